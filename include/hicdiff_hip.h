@@ -1,0 +1,163 @@
+/*
+ * hicdiff_hip.h -- C ABI of libhicdiff_hip.so: the MI355X (gfx950) implementation of HiCDiff's
+ * per-timestep hot path (epsilon-network forward + DDPM / DDRM update) over 1 x S x S Hi-C tiles.
+ *
+ * The reference (BioinfoMachineLearning/hicdiff) is pure Python/PyTorch and has no FFI layer; the
+ * boundary it offers is its Python object contract.  Each entry point below
+ * names the reference call it stands in for (paths relative to the upstream checkout).  The host
+ * side that mirrors the reference classes (hicdiff_amd/) binds these symbols with ctypes; a
+ * maintainer of the reference would add the same binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative HD_E* code; no C++ exception crosses the
+ *     ABI; hd_last_error() gives the message of the last failure on that context;
+ *   - all tensor pointers are DEVICE pointers to contiguous fp32 unless stated otherwise; tiles
+ *     are (B, 1, S, S) row-major exactly as the reference's torch tensors;
+ *   - `stream` is a hipStream_t passed as void*; every call only enqueues work on it: no host
+ *     synchronisation, no allocation (workspace is sized by hd_reserve, called outside capture);
+ *   - one host thread drives one context; contexts are independent (one per GPU / per rank).
+ */
+#ifndef HICDIFF_HIP_H
+#define HICDIFF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hd_ctx hd_ctx;
+
+enum {
+    HD_OK = 0,
+    HD_EINVAL = -1,     /* bad argument / unsupported architecture parameter */
+    HD_ENOWEIGHT = -2,  /* a required state-dict entry is missing or has the wrong shape */
+    HD_EHIP = -3,       /* a HIP runtime call failed */
+    HD_ENOMEM = -4,     /* workspace too small: call hd_reserve(ctx, B) first */
+    HD_ESTATE = -5      /* weights not loaded yet */
+};
+
+enum { HD_ARCH_UNET = 0, HD_ARCH_HICEDRN = 1 };
+
+/* dtype of the per-sample time argument of the epsilon-network */
+enum {
+    HD_T_INT64 = 0,     /* torch.long timesteps, GaussianDiffusion.p_sample (src/hicdiff.py:597) */
+    HD_T_FLOAT32 = 1    /* float timesteps (DDRM, src/functions/denoising.py:49) or SR3 noise level
+                           (B,1) (src/hicdiff_sr3.py:636) */
+};
+
+/* Architecture of the epsilon-network.  Replaces the constructor arguments of
+ *   Unet(dim, dim_mults, channels, self_condition[, noise_level_emb])   src/hicdiff.py:256-269, src/hicdiff_sr3.py:311-324
+ *   hicedrn_Diff(channels, number_resnet, self_condition[, noise_level_emb]) src/model/hicedrn_Diff.py:211-218 */
+typedef struct {
+    int32_t kind;            /* HD_ARCH_UNET | HD_ARCH_HICEDRN */
+    int32_t dim;             /* UNet base width (64; multiple of 16) / hicedrn n_feat (256) */
+    int32_t n_mults;         /* UNet: len(dim_mults) (<= 8) */
+    int32_t mults[8];        /* UNet: dim_mults */
+    int32_t channels;        /* image channels; only 1 is supported (Hi-C tiles) */
+    int32_t self_condition;  /* 1: network input is cat(cond, x) on the channel axis */
+    int32_t sr3;             /* 1: SR3 flavour: noise-level PositionalEncoding + additive FeatureWiseAffine */
+    int32_t groups;          /* UNet GroupNorm groups (8) */
+    int32_t number_resnet;   /* hicedrn residual blocks (32) */
+    int32_t reserved[4];
+} hd_arch_desc;
+
+/* One state-dict entry, named exactly as in the reference checkpoint
+ * (e.g. "downs.0.0.block1.proj.weight"; no "model." prefix). `data` is a device pointer to fp32
+ * in the reference (torch) layout; it is only read during hd_load_weights. */
+typedef struct {
+    const char* name;
+    const void* data;
+    int32_t ndim;
+    int64_t shape[4];
+} hd_named_tensor;
+
+/* Coefficients of one ancestral reverse step, gathered by the host from the 13 schedule buffers of
+ * GaussianDiffusion.__init__ (src/hicdiff.py:494-522) at index t. */
+typedef struct {
+    float sqrt_recip_alphas_cumprod;     /* predict_start_from_noise, src/hicdiff.py:529-533 */
+    float sqrt_recipm1_alphas_cumprod;
+    float posterior_mean_coef1;          /* q_posterior, src/hicdiff.py:553-560 */
+    float posterior_mean_coef2;
+    float sigma;                         /* exp(0.5 * posterior_log_variance_clipped[t]); 0 at t == 0 */
+    float time_value;                    /* value fed to the time embedding: t, or the SR3 noise level */
+} hd_ddpm_coef;
+
+/* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
+typedef struct {
+    float sqrt_at;          /* sqrt(alpha_bar_t) */
+    float sqrt_1m_at;       /* sqrt(1 - alpha_bar_t) */
+    float sqrt_at_next;     /* sqrt(alpha_bar_next) */
+    float sigma_next;       /* sqrt(1 - a_next) / sqrt(a_next) */
+    float sigma_0, etaA, etaB, etaC;
+    float time_value;       /* t as float */
+} hd_ddrm_coef;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* nn.Module construction (Unet.__init__ / hicedrn_Diff.__init__). Selects `device`. */
+int hd_create(hd_ctx** out, int device, const hd_arch_desc* arch);
+void hd_destroy(hd_ctx* ctx);
+const char* hd_last_error(const hd_ctx* ctx);
+const char* hd_version(void);
+
+/* load_state_dict (train.py:186, inference.py:93,104): validates names/shapes against the
+ * architecture, weight-standardises the UNet's 3x3 convs once (src/hicdiff.py:84-97 recomputes it
+ * every forward) and re-packs everything into kernel layout. May be called again after an
+ * optimiser step. Enqueued on `stream`. */
+int hd_load_weights(hd_ctx* ctx, const hd_named_tensor* tensors, int n, void* stream);
+
+/* Workspace for batches of up to B tiles of S x S (grow-only; synchronises the device when it has
+ * to reallocate, so call it outside stream capture). hd_workspace_bytes reports the size. */
+int hd_reserve(hd_ctx* ctx, int B, int S);
+int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+
+/* eps = model(x, t, x_self_cond): Unet.forward src/hicdiff.py:345-387, hicedrn_Diff.forward
+ * src/model/hicedrn_Diff.py:267-289; called from model_predictions (src/hicdiff.py:563), p_losses
+ * (:731) and the DDRM loop (src/functions/denoising.py:57).
+ *   x, eps: (B,1,S,S); cond: (B,1,S,S) or NULL (must be non-NULL iff self_condition);
+ *   t: B elements of t_kind. */
+int hd_eps_forward(hd_ctx* ctx, const float* x, const void* t, int t_kind, const float* cond,
+                   float* eps, int B, int S, void* stream);
+
+/* One fused ancestral step, GaussianDiffusion.p_sample (src/hicdiff.py:594-601; conditional
+ * src/hicdiff_condition.py:592-598; SR3 src/hicdiff_sr3.py:634-652):
+ *   eps = model(x, t, cond); x0 = clamp(c.recip * x - c.recipm1 * eps, -1, 1);
+ *   x <- c.coef1 * x0 + c.coef2 * x + c.sigma * noise.
+ * noise: (B,1,S,S) host-replayed N(0,1) for parity runs, or NULL to draw it on the device
+ * (Philox4x32-10 keyed by (seed, tile_offset + tile, step)); x0_out optional (may be NULL). */
+int hd_ddpm_step(hd_ctx* ctx, float* x_inout, const float* cond, const float* noise,
+                 const hd_ddpm_coef* c, float* x0_out, int B, int S,
+                 uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream);
+
+/* One fused DDRM denoising step (efficient_generalized_steps, src/functions/denoising.py:48-104,
+ * Denoising H: src/functions/svd_replacement.py:148-168):
+ *   eps = model(x, t); x0_t = (x - eps*sqrt(1-a_t))/sqrt(a_t); three-case update against y.
+ * z: 3 x (B,1,S,S) replayed noise (missing / after / before draws, in that order) or NULL for
+ * device Philox. x0_out optional. */
+int hd_ddrm_step(hd_ctx* ctx, float* x_inout, const float* y, const float* z,
+                 const hd_ddrm_coef* c, float* x0_out, int B, int S,
+                 uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream);
+
+/* q_sample (src/hicdiff.py:694-700): out = a[b]*x0 + s[b]*noise with per-sample fp32 coefficients
+ * already gathered by the host side (device pointers, B each). */
+int hd_q_sample(hd_ctx* ctx, const float* x0, const float* noise, const float* a, const float* s,
+                float* out, int B, int S, void* stream);
+
+/* Per-sample loss of p_losses (src/hicdiff.py:743-744): out[b] = mean_pixels(|pred-target|) (l1)
+ * or mean((pred-target)^2) (l2). */
+int hd_loss_per_sample(hd_ctx* ctx, const float* pred, const float* target, int l2, float* out,
+                       int B, int S, void* stream);
+
+/* Fill out (B,1,S,S) with N(0,1) from the device generator (torch.randn stand-in for perf runs,
+ * src/hicdiff.py:607). */
+int hd_randn(hd_ctx* ctx, float* out, int B, int S, uint64_t seed, uint64_t tile_offset,
+             uint32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HICDIFF_HIP_H */

@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE implementation (build container only).
+
+The reference checkout (/root/reference, read-only) is imported as a Python package; no
+reference source is copied.  Weights come from the closed-form fill in oracle/weights.py pushed
+through the reference modules' own ``load_state_dict`` / parameters, inputs from seeded torch
+CPU generators, so the fixtures hold only small inputs and the reference's outputs.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--only NAME]
+
+Every case is also run through the oracle restatement and the max abs difference is printed
+(and asserted) -- that is the oracle's pin against the real reference.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("HICDIFF_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+# src/functions/denoising.py:3 imports torchvision.utils and never uses it; torchvision is absent here.
+sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+sys.modules.setdefault("torchvision.utils", types.ModuleType("torchvision.utils"))
+
+from src import hicdiff as R0                      # noqa: E402  (reference)
+from src import hicdiff_condition as R1            # noqa: E402
+from src import hicdiff_sr3 as R2                  # noqa: E402
+from src.model import hicedrn_Diff as H0           # noqa: E402
+from src.model import hicedrn_sr3_Diff as H2       # noqa: E402
+from src.functions.denoising import efficient_generalized_steps  # noqa: E402
+from src.functions.H_func import MakeFunc          # noqa: E402
+
+from oracle import weights as W                    # noqa: E402
+from oracle import nets as ON                      # noqa: E402
+from oracle import diffusion as OD                 # noqa: E402
+from oracle import ddrm as ODR                     # noqa: E402
+
+torch.set_grad_enabled(False)
+
+
+def tiles(seed, b, s, c=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand((b, c, s, s), generator=g) * 2 - 1
+
+
+def gauss(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g)
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def check(tag, ref, mine, tol=2e-5):
+    d = (ref - mine).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-12)
+    print(f"  [{tag}] oracle vs reference: max|d|={d:.3e} (rel {d / scale:.3e})")
+    assert d / scale <= tol, f"oracle disagrees with reference on {tag}"
+
+
+# ------------------------------------------------------------------ builders
+
+def build_unet(kind, dim=64, mults=(1, 2, 4, 8)):
+    if kind == "uncond":
+        m = R0.Unet(dim=dim, dim_mults=mults, channels=1, self_condition=False)
+    elif kind == "cond":
+        m = R1.Unet(dim=dim, dim_mults=mults, channels=1, self_condition=True)
+    else:
+        m = R2.Unet(dim=dim, dim_mults=mults, channels=1, self_condition=True, noise_level_emb=True)
+    W.fill_module_(m)
+    m.eval()
+    cfg = ON.UnetCfg(dim=dim, dim_mults=tuple(mults), self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    return m, cfg
+
+
+def build_hicedrn(kind, nres):
+    if kind == "uncond":
+        m = H0.hicedrn_Diff(number_resnet=nres, self_condition=False)
+    elif kind == "cond":
+        m = H0.hicedrn_Diff(number_resnet=nres, self_condition=True)
+    else:
+        m = H2.hicedrn_Diff(number_resnet=nres, self_condition=True, noise_level_emb=True)
+    W.fill_module_(m)
+    m.eval()
+    cfg = ON.HicedrnCfg(number_resnet=nres, self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    return m, cfg
+
+
+def oracle_model(m, cfg):
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    return ON.make_eps_fn(sd, cfg)
+
+
+# ------------------------------------------------------------------ cases
+
+def case_param_inventory():
+    """Reference state_dict key order and shapes for every architecture flavour."""
+    inv = {}
+    for kind in ("uncond", "cond", "sr3"):
+        m, _ = build_unet(kind)
+        inv["unet_" + kind] = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+        mine = W.unet_shapes(self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+        assert [(k, list(s)) for k, s in mine.items()] == inv["unet_" + kind], kind
+        m, _ = build_hicedrn(kind, 32)
+        inv["hicedrn_" + kind] = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+        mine = W.hicedrn_shapes(self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+        assert [(k, list(s)) for k, s in mine.items()] == inv["hicedrn_" + kind], kind
+    d = R0.GaussianDiffusion(build_unet("uncond", 16, (1, 2))[0], image_size=16, timesteps=10, beta_schedule="linear")
+    inv["diffusion_buffers"] = [(k, list(v.shape)) for k, v in d.state_dict().items() if not k.startswith("model.")]
+    import json
+    with open(os.path.join(HERE, "param_inventory.json"), "w") as f:
+        json.dump(inv, f)
+    print("  wrote param_inventory.json")
+
+
+def case_schedules():
+    out = {}
+    tiny, _ = build_unet("uncond", 16, (1, 2))
+    for sched, T in (("linear", 50), ("linear", 1000), ("linear", 2000), ("sigmoid", 1000), ("sigmoid", 2000), ("cosine", 1000)):
+        d = R0.GaussianDiffusion(tiny, image_size=16, timesteps=T, beta_schedule=sched)
+        mine = OD.diffusion_buffers(sched, T)
+        for name in OD.BUFFER_NAMES:
+            out[f"{sched}_{T}_{name}"] = getattr(d, name)
+            assert torch.equal(getattr(d, name), mine[name]), (sched, T, name)
+    tcond, _ = build_unet("sr3", 16, (1, 2))
+    d = R2.GaussianDiffusion(tcond, image_size=16, timesteps=2000, beta_schedule="linear")
+    out["linear_2000_sqrt_alphas_cumprod_prev"] = d.sqrt_alphas_cumprod_prev
+    assert torch.equal(d.sqrt_alphas_cumprod_prev, OD.diffusion_buffers("linear", 2000)["sqrt_alphas_cumprod_prev"])
+    # DDRM's own beta table (src/Utils/metrics_diff.py:36-81) is numpy based; restated in oracle.ddrm
+    out["ddrm_linear_betas"] = ODR.ddrm_betas("linear")
+    save("schedules", **out)
+
+
+def _eps_case(name, m, cfg, x, t, cond):
+    ref = m(x, t, cond) if cond is not None else m(x, t)
+    mine = oracle_model(m, cfg)(x, t, cond)
+    check(name, ref, mine)
+    arrays = dict(x=x, t=t, eps=ref)
+    if cond is not None:
+        arrays["cond"] = cond
+    return arrays
+
+
+def case_eps():
+    out = {}
+    for kind in ("uncond", "cond", "sr3"):
+        m, cfg = build_unet(kind)
+        for tag, b, s, seed in (("s40", 2, 40, 11), ("s64", 1, 64, 12)):
+            x = tiles(seed, b, s)
+            cond = tiles(seed + 100, b, s) if kind != "uncond" else None
+            if kind == "sr3":
+                t = torch.tensor([[0.9731], [0.2104]][:b], dtype=torch.float32)
+            else:
+                t = torch.tensor([27, 999][:b] if b > 1 else [500])
+            for k, v in _eps_case(f"unet_{kind}_{tag}", m, cfg, x, t, cond).items():
+                out[f"unet_{kind}_{tag}_{k}"] = v
+    # float-valued timesteps, as the DDRM sampler passes them (src/functions/denoising.py:49,57)
+    m, cfg = build_unet("uncond")
+    x = tiles(13, 2, 40)
+    t = torch.ones(2) * 980
+    for k, v in _eps_case("unet_uncond_floatt", m, cfg, x, t, None).items():
+        out[f"unet_uncond_floatt_{k}"] = v
+    # hicedrn: one full 32-block net, 3-block nets for the conditional flavours
+    for kind, nres, b, s, seed in (("uncond", 32, 1, 40, 21), ("uncond", 3, 2, 64, 22), ("cond", 3, 2, 64, 23), ("sr3", 3, 2, 40, 24)):
+        m, cfg = build_hicedrn(kind, nres)
+        x = tiles(seed, b, s)
+        cond = tiles(seed + 100, b, s) if kind != "uncond" else None
+        t = torch.tensor([[0.731], [0.0504]][:b]) if kind == "sr3" else torch.tensor([3, 640][:b] if b > 1 else [500])
+        for k, v in _eps_case(f"hicedrn_{kind}_n{nres}_s{s}", m, cfg, x, t, cond).items():
+            out[f"hicedrn_{kind}_n{nres}_s{s}_{k}"] = v
+    save("eps", **out)
+
+
+def case_tiny():
+    """Unet(dim=16, dim_mults=(1,2)) with per-stage probes, for fast op-order debugging."""
+    out = {}
+    for kind in ("uncond", "cond", "sr3"):
+        m, cfg = build_unet(kind, 16, (1, 2))
+        for s, b, seed in ((16, 3, 31), (40, 2, 32)):
+            x = tiles(seed, b, s)
+            cond = tiles(seed + 100, b, s) if kind != "uncond" else None
+            t = torch.tensor([[0.9], [0.5], [0.1]][:b]) if kind == "sr3" else torch.tensor([0, 499, 999][:b])
+            ref = m(x, t, cond) if cond is not None else m(x, t)
+            probes = {}
+            sd = {k: v.clone() for k, v in m.state_dict().items()}
+            mine = ON.unet_eps(sd, x, t, cond, cfg, probes)
+            check(f"tiny_{kind}_s{s}", ref, mine)
+            pre = f"{kind}_s{s}_"
+            out[pre + "x"], out[pre + "t"], out[pre + "eps"] = x, t, ref
+            if cond is not None:
+                out[pre + "cond"] = cond
+            if kind == "uncond" and s == 16:
+                # probes come from hooks on the reference modules, not from the oracle
+                got = {}
+                hooks = [m.init_conv.register_forward_hook(lambda _m, _i, o: got.__setitem__("init_conv", o)),
+                         m.time_mlp.register_forward_hook(lambda _m, _i, o: got.__setitem__("time_mlp", o)),
+                         m.downs[0][0].register_forward_hook(lambda _m, _i, o: got.__setitem__("downs.0.0", o)),
+                         m.downs[0][2].register_forward_hook(lambda _m, _i, o: got.__setitem__("downs.0.2", o)),
+                         m.downs[0][3].register_forward_hook(lambda _m, _i, o: got.__setitem__("downs.0", o)),
+                         m.mid_attn.register_forward_hook(lambda _m, _i, o: got.__setitem__("mid_attn", o)),
+                         m.mid_block2.register_forward_hook(lambda _m, _i, o: got.__setitem__("mid", o)),
+                         m.ups[0][3].register_forward_hook(lambda _m, _i, o: got.__setitem__("ups.0", o)),
+                         m.final_res_block.register_forward_hook(lambda _m, _i, o: got.__setitem__("final_res", o))]
+                m(x, t)
+                for h in hooks:
+                    h.remove()
+                for k, v in got.items():
+                    out[pre + "probe_" + k] = v
+                for k in ("init_conv", "time_mlp", "downs.0", "mid", "ups.0"):
+                    check(f"tiny probe {k}", got[k], probes[k])
+    save("tiny", **out)
+
+
+def _kept(imgs, T, every):
+    # reference returns the list [x_T, x_{T-1}, ..., x_0]; index T - t holds x after step t
+    return {t: imgs[T - t] for t in range(0, T, every)}
+
+
+def case_trajectories():
+    out = {}
+    T, B, S, every = 50, 2, 40, 10
+    # (i) unconditional ancestral chain, GaussianDiffusion.sample (src/hicdiff.py:603-620,666-671)
+    m, cfg = build_unet("uncond")
+    d = R0.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+    torch.manual_seed(1234)
+    stack = d.sample(torch.zeros(B, 1, S, S), return_all_timesteps=True)          # (B, T+1, 1, S, S)
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+    final, kept = oref.p_sample_loop((B, 1, S, S), OD.TorchNoise(1234), keep_every=every)
+    out["uncond_xT"] = stack[:, 0]
+    for t in range(0, T, every):
+        out[f"uncond_x_after_t{t}"] = stack[:, T - t]
+        check(f"uncond chain x after t={t}", stack[:, T - t], kept[t], tol=5e-4)
+    # (ii) conditional chain, super_resolution (src/hicdiff_condition.py:600-623,676-678)
+    m, cfg = build_unet("cond")
+    d = R1.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+    lq = tiles(77, B, S)
+    torch.manual_seed(4321)
+    ret = d.super_resolution(lq, True)                                             # list of T+2 tensors
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="cond")
+    final, kept = oref.p_sample_loop(lq, OD.TorchNoise(4321), keep_every=every)
+    out["cond_lq"] = lq
+    for t in range(0, T, every):
+        out[f"cond_x_after_t{t}"] = ret[T - t]
+        check(f"cond chain x after t={t}", ret[T - t], kept[t], tol=5e-4)
+    # (iii) SR3 chain (src/hicdiff_sr3.py:634-676)
+    m, cfg = build_unet("sr3")
+    d = R2.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+    torch.manual_seed(999)
+    ret = d.super_resolution(lq, True)
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="sr3")
+    final, kept = oref.p_sample_loop(lq, OD.TorchNoise(999), keep_every=every)
+    for t in range(0, T, every):
+        out[f"sr3_x_after_t{t}"] = ret[T - t]
+        check(f"sr3 chain x after t={t}", ret[T - t], kept[t], tol=5e-4)
+    # (iv) DDIM, 20 of 1000 steps, eta 0 and 0.5 (src/hicdiff.py:622-664)
+    m, cfg = build_unet("uncond")
+    for eta in (0.0, 0.5):
+        d = R0.GaussianDiffusion(m, image_size=S, timesteps=1000, sampling_timesteps=20, loss_type="l2",
+                                 beta_schedule="sigmoid", ddim_sampling_eta=eta)
+        torch.manual_seed(55)
+        x = d.sample(torch.zeros(B, 1, S, S))
+        oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=1000, beta_schedule="sigmoid",
+                               sampling_timesteps=20, ddim_sampling_eta=eta)
+        mine = oref.ddim_sample((B, 1, S, S), OD.TorchNoise(55))
+        check(f"ddim eta={eta}", x, mine, tol=5e-4)
+        out[f"ddim_eta{eta}_x0"] = x
+    # (v) DDRM 'deno', 50 of 1000 steps: the inference.py -u 1 path with a UNet and with hicedrn
+    betas = ODR.ddrm_betas("linear")
+    seq = range(0, 1000, 20)
+    hq = tiles(88, B, S)
+    for net in ("unet", "hicedrn3"):
+        m, cfg = build_unet("uncond") if net == "unet" else build_hicedrn("uncond", 3)
+        for sigma_0 in (0.1, 1.0):
+            y0 = (hq + sigma_0 * gauss(89, hq.shape)).reshape(B, -1)
+            H = MakeFunc("deno", 1, S, device=None)
+            torch.manual_seed(2024)
+            x = torch.randn(B, 1, S, S)
+            xs, x0s = efficient_generalized_steps(x, seq, m, betas, H, y0, sigma_0, etaB=1.0, etaA=0.85, etaC=0.85)
+            nz = OD.TorchNoise(2024)
+            x_m = nz.randn((B, 1, S, S))
+            assert torch.equal(x, x_m)
+            mine, x0_m, kept = ODR.ddrm_denoise(x_m, seq, oracle_model(m, cfg), betas, y0, sigma_0, noise=nz,
+                                                keep_steps=(10, 25, 40))
+            check(f"ddrm {net} sigma0={sigma_0} final", xs[-1], mine, tol=5e-4)
+            check(f"ddrm {net} sigma0={sigma_0} x0_t", x0s[-1], x0_m, tol=5e-4)
+            pre = f"ddrm_{net}_s{sigma_0}_"
+            out[pre + "y0"], out[pre + "final"], out[pre + "x0_last"] = y0, xs[-1], x0s[-1]
+            # xs[k] is the state after the k-th executed step; steps run i = 980, 960, ..., 0
+            for k in kept:
+                out[pre + f"x_step{k}"] = xs[k]
+                check(f"ddrm {net} sigma0={sigma_0} step {k}", xs[k], kept[k], tol=5e-4)
+    save("trajectories", **out)
+
+
+def case_losses():
+    out = {}
+    B, S, T = 4, 40, 1000
+    x0 = tiles(5, B, S)
+    lq = tiles(6, B, S)
+    for loss in ("l1", "l2"):
+        m, cfg = build_unet("uncond")
+        d = R0.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type=loss, beta_schedule="sigmoid")
+        torch.manual_seed(100)
+        val = d(x0)
+        torch.manual_seed(100)
+        t = torch.randint(0, T, (B,)).long()
+        eps = torch.randn_like(x0)
+        oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="sigmoid", loss_type=loss)
+        check(f"p_losses uncond {loss}", val, oref.p_losses(x0, t, eps))
+        out[f"uncond_{loss}_t"], out[f"uncond_{loss}_eps"], out[f"uncond_{loss}_loss"] = t, eps, val
+    m, cfg = build_unet("cond")
+    d = R1.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+    torch.manual_seed(101)
+    val = d([lq, x0])
+    torch.manual_seed(101)
+    t = torch.randint(0, T, (B,)).long()
+    eps = torch.randn_like(x0)
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="cond")
+    check("p_losses cond l2", val, oref.p_losses(x0, t, eps, lq))
+    out["cond_l2_t"], out["cond_l2_eps"], out["cond_l2_loss"] = t, eps, val
+    m, cfg = build_unet("sr3")
+    d = R2.GaussianDiffusion(m, image_size=S, timesteps=2000, loss_type="l2", beta_schedule="linear")
+    np.random.seed(7)
+    torch.manual_seed(102)
+    val = d([lq, x0])
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=2000, beta_schedule="linear", loss_type="l2", kind="sr3")
+    level = oref.sr3_draw_level(np.random.RandomState(7), B)
+    torch.manual_seed(102)
+    eps = torch.randn_like(x0)
+    check("p_losses sr3 l2", val, oref.p_losses_sr3(x0, level, eps, lq))
+    out["sr3_l2_level"], out["sr3_l2_eps"], out["sr3_l2_loss"] = level, eps, val
+    out["x0"], out["lq"] = x0, lq
+    # q_sample on its own (src/hicdiff.py:694-700)
+    out["q_sample_t"] = torch.tensor([0, 10, 500, 999])
+    out["q_sample_out"] = R0.GaussianDiffusion(m, image_size=S, timesteps=T, beta_schedule="sigmoid").q_sample(
+        x0, out["q_sample_t"], out["uncond_l2_eps"])
+    save("losses", **out)
+
+
+CASES = {
+    "inventory": case_param_inventory,
+    "schedules": case_schedules,
+    "eps": case_eps,
+    "tiny": case_tiny,
+    "trajectories": case_trajectories,
+    "losses": case_losses,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, choices=sorted(CASES))
+    args = ap.parse_args()
+    for name, fn in CASES.items():
+        if args.only and name != args.only:
+            continue
+        print(f"== {name}")
+        fn()
