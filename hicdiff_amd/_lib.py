@@ -1,0 +1,88 @@
+"""ctypes binding of libhicdiff_hip.so (the C ABI declared in include/hicdiff_hip.h).
+
+There is no fallback: if the shared library is missing or a symbol is absent, importing the
+product path raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C hicdiff_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhicdiff_hip.so")
+
+HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -4, -5
+HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
+HD_T_INT64, HD_T_FLOAT32 = 0, 1
+
+
+class HdArchDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("dim", C.c_int32), ("n_mults", C.c_int32), ("mults", C.c_int32 * 8),
+        ("channels", C.c_int32), ("self_condition", C.c_int32), ("sr3", C.c_int32), ("groups", C.c_int32),
+        ("number_resnet", C.c_int32), ("reserved", C.c_int32 * 4),
+    ]
+
+
+class HdNamedTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class HdDdpmCoef(C.Structure):
+    _fields_ = [
+        ("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
+        ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
+        ("sigma", C.c_float), ("time_value", C.c_float),
+    ]
+
+
+class HdDdrmCoef(C.Structure):
+    _fields_ = [
+        ("sqrt_at", C.c_float), ("sqrt_1m_at", C.c_float), ("sqrt_at_next", C.c_float), ("sigma_next", C.c_float),
+        ("sigma_0", C.c_float), ("etaA", C.c_float), ("etaB", C.c_float), ("etaC", C.c_float), ("time_value", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+# symbol -> (restype, argtypes); exactly the declarations of include/hicdiff_hip.h
+SYMBOLS = {
+    "hd_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(HdArchDesc)]),
+    "hd_destroy": (None, [_P]),
+    "hd_last_error": (C.c_char_p, [_P]),
+    "hd_version": (C.c_char_p, []),
+    "hd_load_weights": (C.c_int, [_P, C.POINTER(HdNamedTensor), C.c_int, _P]),
+    "hd_reserve": (C.c_int, [_P, C.c_int, C.c_int]),
+    "hd_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
+    "hd_eps_forward": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "hd_ddpm_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(HdDdpmCoef), _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "hd_ddrm_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(HdDdrmCoef), _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+    "hd_q_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "hd_loss_per_sample": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library once; raise (never fall back) when it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the HiCDiff hot path has no CPU/PyTorch fallback. "
+            "Build it with `make -C hicdiff_amd/csrc` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class HdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"hicdiff_hip error {code}: {msg}")
+        self.code = code

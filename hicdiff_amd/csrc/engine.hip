@@ -1,0 +1,747 @@
+// HiCDiff engine for gfx950: network plans (UNet / hicedrn, unconditional, conditional, SR3), weight
+// packing, activation pool, and the C ABI of include/hicdiff_hip.h.
+#include "hd_common.h"
+#include "../../include/hicdiff_hip.h"
+#include "../../include/hicdiff_hip_debug.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static thread_local std::string g_err;
+void hd_set_error(const std::string& msg) { g_err = msg; }
+
+#define HD_TRY(expr)                  \
+    do {                              \
+        int rc_ = (expr);             \
+        if (rc_ != 0) return rc_;     \
+    } while (0)
+
+// ---- activation pool: first-fit free list over one device block; deterministic for a given call
+// sequence, so a captured graph always sees the same addresses.  `dry` simulates the same sequence
+// on an unbounded arena to size the block (hd_workspace_bytes / hd_reserve).
+struct Pool {
+    char* base = nullptr;
+    size_t cap = 0;
+    bool dry = false;
+    size_t high = 0;
+    std::vector<std::pair<size_t, size_t>> free_;   // (offset, size), sorted by offset
+    std::unordered_map<size_t, size_t> live;        // offset -> size
+    void reset(bool dry_) {
+        dry = dry_; high = 0; free_.clear(); live.clear();
+        free_.push_back({0, dry ? (size_t)1 << 60 : cap});
+    }
+    bool alloc(size_t bytes, float** out) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (size_t i = 0; i < free_.size(); ++i) {
+            if (free_[i].second >= bytes) {
+                size_t off = free_[i].first;
+                free_[i].first += bytes; free_[i].second -= bytes;
+                if (free_[i].second == 0) free_.erase(free_.begin() + i);
+                live[off] = bytes;
+                high = std::max(high, off + bytes);
+                *out = dry ? reinterpret_cast<float*>((uintptr_t)256 + off) : reinterpret_cast<float*>(base + off);
+                return true;
+            }
+        }
+        return false;
+    }
+    void release(float* p) {
+        if (!p) return;
+        size_t off = dry ? (size_t)((uintptr_t)p - 256) : (size_t)((char*)p - base);
+        auto it = live.find(off);
+        if (it == live.end()) return;
+        size_t sz = it->second;
+        live.erase(it);
+        auto pos = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (size_t)0));
+        pos = free_.insert(pos, {off, sz});
+        size_t i = pos - free_.begin();
+        if (i + 1 < free_.size() && free_[i].first + free_[i].second == free_[i + 1].first) {
+            free_[i].second += free_[i + 1].second; free_.erase(free_.begin() + i + 1);
+        }
+        if (i > 0 && free_[i - 1].first + free_[i - 1].second == free_[i].first) {
+            free_[i - 1].second += free_[i].second; free_.erase(free_.begin() + i);
+        }
+    }
+};
+
+struct ResW {
+    ConvW c1, c2, res;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    bool has_res = false, has_norm = true;
+    int film_off = 0, cin = 0, cout = 0;
+    std::string name;
+};
+struct AttnW {
+    float* norm_g = nullptr; float* out_g = nullptr;
+    ConvW qkv, out;
+    int dim = 0; bool linear = true;
+    std::string name;
+};
+struct StageW { ResW r1, r2; AttnW attn; ConvW resample; bool last = false; int cin = 0, cout = 0; };
+
+struct hd_ctx {
+    hd_arch_desc arch{};
+    int device = 0;
+    bool loaded = false;
+    std::string err;
+    std::vector<void*> owned;      // every weight allocation
+    // shared
+    float *first_w = nullptr, *first_b = nullptr;   // init_conv / head, torch layout
+    int first_ks = 7, first_cout = 64, cin0 = 1;
+    int time_in = 64, time_dim = 256;
+    float *w1t = nullptr, *b1 = nullptr, *w3t = nullptr, *b3 = nullptr;
+    float *film_wt = nullptr, *film_b = nullptr; int film_n = 0;
+    // unet
+    std::vector<StageW> downs, ups;
+    ResW mid1, mid2, final_res; AttnW mid_attn;
+    float *final_w = nullptr, *final_b = nullptr;
+    // hicedrn
+    std::vector<ResW> body; ConvW body_tail, tail;
+    // workspace
+    Pool pool;
+    float* eps_buf = nullptr; size_t eps_cap = 0;   // eps of the fused step calls
+    int resB = 0, resS = 0;
+    // test-only capture of intermediates (hicdiff_hip_debug.h)
+    bool capture = false;
+    std::unordered_map<std::string, Act> captured;
+};
+
+static int fail(hd_ctx* c, int code, const std::string& msg) {
+    g_err = msg;
+    if (c) c->err = msg;
+    return code;
+}
+static int keep_err(hd_ctx* c, int rc) { if (rc != 0 && c) c->err = g_err; return rc; }
+
+// ---- weights -----------------------------------------------------------------------------------
+struct Loader {
+    hd_ctx* c; hipStream_t st;
+    std::unordered_map<std::string, const hd_named_tensor*> map;
+    const hd_named_tensor* get(const std::string& name, std::initializer_list<int64_t> shape) {
+        auto it = map.find(name);
+        if (it == map.end()) { fail(c, HD_ENOWEIGHT, "missing state-dict entry '" + name + "'"); return nullptr; }
+        const hd_named_tensor* t = it->second;
+        bool ok = t->ndim == (int)shape.size();
+        int i = 0;
+        for (int64_t s : shape) { if (ok && t->shape[i] != s) ok = false; ++i; }
+        if (!ok) { fail(c, HD_ENOWEIGHT, "state-dict entry '" + name + "' has the wrong shape"); return nullptr; }
+        return t;
+    }
+    float* dev(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(float)) != hipSuccess) { fail(c, HD_EHIP, "hipMalloc(weights) failed"); return nullptr; }
+        c->owned.push_back(p);
+        return (float*)p;
+    }
+    // copy a small 1-D style parameter
+    int vec(const std::string& name, std::initializer_list<int64_t> shape, float** dst) {
+        const hd_named_tensor* t = get(name, shape);
+        if (!t) return HD_ENOWEIGHT;
+        size_t n = 1; for (int64_t s : shape) n *= (size_t)s;
+        if (!*dst) { *dst = dev(n); if (!*dst) return HD_EHIP; }
+        if (hipMemcpyAsync(*dst, t->data, n * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(c, HD_EHIP, "weight copy failed");
+        return 0;
+    }
+    int conv(const std::string& name, int cout, int cin, int k, bool standardize, bool unshuffle, bool bias, ConvW* w) {
+        const hd_named_tensor* t = unshuffle ? get(name + ".weight", {cout, (int64_t)cin * 4, 1, 1}) : get(name + ".weight", {cout, cin, k, k});
+        if (!t) return HD_ENOWEIGHT;
+        const int KH = unshuffle ? 2 : k;
+        w->KH = w->KW = KH; w->Cin = cin; w->Cout = cout; w->CoutPad = (cout + 63) / 64 * 64;
+        if (!w->w) { w->w = dev((size_t)KH * KH * cin * w->CoutPad); if (!w->w) return HD_EHIP; }
+        HD_TRY(launch_pack_conv((const float*)t->data, w->w, cout, cin, KH, KH, w->CoutPad, standardize ? 1 : 0, unshuffle ? 1 : 0, st));
+        if (bias) HD_TRY(vec(name + ".bias", {cout}, &w->bias));
+        return 0;
+    }
+};
+
+static int load_film(Loader& L, const std::string& name, int nout, int* off_io, int* my_off) {
+    hd_ctx* c = L.c;
+    const bool sr3 = c->arch.sr3;
+    const std::string key = name + (sr3 ? ".noise_func.noise_func.0" : ".mlp.1");
+    const hd_named_tensor* w = L.get(key + ".weight", {nout, c->time_dim});
+    const hd_named_tensor* b = L.get(key + ".bias", {nout});
+    if (!w || !b) return HD_ENOWEIGHT;
+    *my_off = *off_io;
+    HD_TRY(launch_transpose((const float*)w->data, c->film_wt, nout, c->time_dim, c->film_n, *off_io, L.st));
+    if (hipMemcpyAsync(c->film_b + *off_io, b->data, (size_t)nout * sizeof(float), hipMemcpyDeviceToDevice, L.st) != hipSuccess)
+        return fail(c, HD_EHIP, "film bias copy failed");
+    *off_io += nout;
+    return 0;
+}
+
+static int load_unet_res(Loader& L, const std::string& p, int cin, int cout, ResW* r, int* film_off) {
+    const bool sr3 = L.c->arch.sr3;
+    r->name = p; r->cin = cin; r->cout = cout; r->has_res = cin != cout; r->has_norm = true;
+    HD_TRY(load_film(L, p, sr3 ? cout : 2 * cout, film_off, &r->film_off));
+    HD_TRY(L.conv(p + ".block1.proj", cout, cin, 3, true, false, true, &r->c1));
+    HD_TRY(L.vec(p + ".block1.norm.weight", {cout}, &r->g1));
+    HD_TRY(L.vec(p + ".block1.norm.bias", {cout}, &r->b1));
+    HD_TRY(L.conv(p + ".block2.proj", cout, cout, 3, true, false, true, &r->c2));
+    HD_TRY(L.vec(p + ".block2.norm.weight", {cout}, &r->g2));
+    HD_TRY(L.vec(p + ".block2.norm.bias", {cout}, &r->b2));
+    if (r->has_res) HD_TRY(L.conv(p + ".res_conv", cout, cin, 1, false, false, true, &r->res));
+    return 0;
+}
+
+static int load_attn(Loader& L, const std::string& p, int dim, bool linear, AttnW* a) {
+    a->name = p; a->dim = dim; a->linear = linear;
+    HD_TRY(L.vec(p + ".fn.norm.g", {1, dim, 1, 1}, &a->norm_g));
+    HD_TRY(L.conv(p + ".fn.fn.to_qkv", 384, dim, 1, false, false, false, &a->qkv));
+    if (linear) {
+        HD_TRY(L.conv(p + ".fn.fn.to_out.0", dim, 128, 1, false, false, true, &a->out));
+        HD_TRY(L.vec(p + ".fn.fn.to_out.1.g", {1, dim, 1, 1}, &a->out_g));
+    } else {
+        HD_TRY(L.conv(p + ".fn.fn.to_out", dim, 128, 1, false, false, true, &a->out));
+    }
+    return 0;
+}
+
+static int unet_film_total(const hd_arch_desc& a) {
+    const int per = a.sr3 ? 1 : 2;
+    int total = 0, d_prev = a.dim;
+    std::vector<int> dims{a.dim};
+    for (int i = 0; i < a.n_mults; ++i) dims.push_back(a.dim * a.mults[i]);
+    for (int i = 0; i < a.n_mults; ++i) total += 2 * per * dims[i];          // downs: blocks are dim_in -> dim_in
+    total += 2 * per * dims.back();                                           // mid blocks
+    for (int i = a.n_mults - 1; i >= 0; --i) total += 2 * per * dims[i + 1];  // ups: blocks produce dim_out
+    total += per * a.dim;                                                     // final_res_block
+    (void)d_prev;
+    return total;
+}
+
+static int load_common_time(Loader& L, const std::string& first) {
+    hd_ctx* c = L.c;
+    const hd_named_tensor* w1 = L.get("time_mlp.1.weight", {c->time_dim, c->time_in});
+    const hd_named_tensor* w3 = L.get("time_mlp.3.weight", {c->time_dim, c->time_dim});
+    if (!w1 || !w3) return HD_ENOWEIGHT;
+    if (!c->w1t) { c->w1t = L.dev((size_t)c->time_in * c->time_dim); c->w3t = L.dev((size_t)c->time_dim * c->time_dim); }
+    if (!c->w1t || !c->w3t) return HD_EHIP;
+    HD_TRY(launch_transpose((const float*)w1->data, c->w1t, c->time_dim, c->time_in, c->time_dim, 0, L.st));
+    HD_TRY(launch_transpose((const float*)w3->data, c->w3t, c->time_dim, c->time_dim, c->time_dim, 0, L.st));
+    HD_TRY(L.vec("time_mlp.1.bias", {c->time_dim}, &c->b1));
+    HD_TRY(L.vec("time_mlp.3.bias", {c->time_dim}, &c->b3));
+    HD_TRY(L.vec(first + ".weight", {c->first_cout, c->cin0, c->first_ks, c->first_ks}, &c->first_w));
+    HD_TRY(L.vec(first + ".bias", {c->first_cout}, &c->first_b));
+    if (!c->film_wt) { c->film_wt = L.dev((size_t)c->time_dim * c->film_n); c->film_b = L.dev(c->film_n); }
+    if (!c->film_wt || !c->film_b) return HD_EHIP;
+    return 0;
+}
+
+static int load_unet(Loader& L) {
+    hd_ctx* c = L.c;
+    const hd_arch_desc& a = c->arch;
+    HD_TRY(load_common_time(L, "init_conv"));
+    std::vector<int> dims{a.dim};
+    for (int i = 0; i < a.n_mults; ++i) dims.push_back(a.dim * a.mults[i]);
+    const int n = a.n_mults;
+    c->downs.resize(n); c->ups.resize(n);
+    int off = 0;
+    for (int i = 0; i < n; ++i) {
+        StageW& s = c->downs[i];
+        const int di = dims[i], dout = dims[i + 1];
+        const std::string p = "downs." + std::to_string(i);
+        s.cin = di; s.cout = dout; s.last = i >= n - 1;
+        HD_TRY(load_unet_res(L, p + ".0", di, di, &s.r1, &off));
+        HD_TRY(load_unet_res(L, p + ".1", di, di, &s.r2, &off));
+        HD_TRY(load_attn(L, p + ".2", di, true, &s.attn));
+        if (s.last) HD_TRY(L.conv(p + ".3", dout, di, 3, false, false, true, &s.resample));
+        else HD_TRY(L.conv(p + ".3.1", dout, di, 1, false, true, true, &s.resample));
+    }
+    const int mid = dims.back();
+    HD_TRY(load_unet_res(L, "mid_block1", mid, mid, &c->mid1, &off));
+    HD_TRY(load_attn(L, "mid_attn", mid, false, &c->mid_attn));
+    HD_TRY(load_unet_res(L, "mid_block2", mid, mid, &c->mid2, &off));
+    for (int i = 0; i < n; ++i) {
+        StageW& s = c->ups[i];
+        const int di = dims[n - 1 - i], dout = dims[n - i];   // reversed(in_out)[i] = (dim_in, dim_out)
+        const std::string p = "ups." + std::to_string(i);
+        s.cin = di; s.cout = dout; s.last = i == n - 1;
+        HD_TRY(load_unet_res(L, p + ".0", dout + di, dout, &s.r1, &off));
+        HD_TRY(load_unet_res(L, p + ".1", dout + di, dout, &s.r2, &off));
+        HD_TRY(load_attn(L, p + ".2", dout, true, &s.attn));
+        if (s.last) HD_TRY(L.conv(p + ".3", di, dout, 3, false, false, true, &s.resample));
+        else HD_TRY(L.conv(p + ".3.1", di, dout, 3, false, false, true, &s.resample));
+    }
+    HD_TRY(load_unet_res(L, "final_res_block", a.dim * 2, a.dim, &c->final_res, &off));
+    HD_TRY(L.vec("final_conv.weight", {1, a.dim, 1, 1}, &c->final_w));
+    HD_TRY(L.vec("final_conv.bias", {1}, &c->final_b));
+    if (off != c->film_n) return fail(c, HD_EINVAL, "internal: FiLM column count mismatch");
+    return 0;
+}
+
+static int load_hicedrn(Loader& L) {
+    hd_ctx* c = L.c;
+    const hd_arch_desc& a = c->arch;
+    HD_TRY(load_common_time(L, "head"));
+    const int F = a.dim;
+    c->body.resize(a.number_resnet);
+    int off = 0;
+    for (int i = 0; i < a.number_resnet; ++i) {
+        ResW& r = c->body[i];
+        const std::string p = "body." + std::to_string(i);
+        r.name = p; r.cin = r.cout = F; r.has_norm = false;
+        HD_TRY(load_film(L, p, a.sr3 ? F : 2 * F, &off, &r.film_off));
+        HD_TRY(L.conv(p + ".conv.proj", F, F, 3, false, false, true, &r.c1));
+    }
+    HD_TRY(L.conv("body_tail", F, F, 3, false, false, true, &c->body_tail));
+    HD_TRY(L.conv("tail", 1, F, 3, false, false, true, &c->tail));
+    return 0;
+}
+
+// ---- forward plans -----------------------------------------------------------------------------
+struct Run {
+    hd_ctx* c; hipStream_t st; bool dry;
+    int B, S;
+    // time embedding rows: Bt == B (per-sample t) or 1 (every tile at the same step)
+    int Bt; const float* film; int film_bs;
+    int alloc(size_t n, float** p) {
+        if (!c->pool.alloc(n * sizeof(float), p)) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) with the batch and tile size first");
+        return 0;
+    }
+    int act(int H, int W, int C, Act* a) { a->B = B; a->H = H; a->W = W; a->C = C; return alloc(a->numel(), &a->p); }
+    void free(float* p) { c->pool.release(p); }
+    void free(Act& a) { c->pool.release(a.p); a.p = nullptr; }
+};
+
+static int probe(Run& r, const std::string& label, const Act& a) {
+    hd_ctx* c = r.c;
+    if (r.dry || !c->capture) return 0;
+    Act copy = a;
+    void* p = nullptr;
+    if (hipMalloc(&p, a.numel() * sizeof(float)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(capture) failed");
+    if (hipMemcpyAsync(p, a.p, a.numel() * sizeof(float), hipMemcpyDeviceToDevice, r.st) != hipSuccess) return fail(c, HD_EHIP, "capture copy failed");
+    copy.p = (float*)p;
+    auto it = c->captured.find(label);
+    if (it != c->captured.end()) { (void)hipFree(it->second.p); }
+    c->captured[label] = copy;
+    return 0;
+}
+
+static int run_conv(Run& r, ConvArgs& a) {
+    if (r.dry) return 0;
+    return launch_conv(a, r.st, nullptr);
+}
+
+// GroupNorm'd conv of the UNet: conv (+ fused per-channel partial sums when the tile geometry allows)
+// followed by gn_finalize -> per-(sample, channel) affine (A, Bv[, E]).
+static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* beta, int film_mode, int film_off,
+                   float** A, float** Bv, float** E) {
+    const int HW = a.H * a.W;
+    int slots = conv_gn_slots(a.B, a.H, a.W, C);
+    const bool fused = slots > 0;
+    if (!fused) slots = (HW + 255) / 256;
+    float* part = nullptr;
+    HD_TRY(r.alloc((size_t)a.B * slots * C * 2, &part));
+    a.gn_part = fused ? part : nullptr;
+    HD_TRY(run_conv(r, a));
+    if (!fused && !r.dry) { int s2 = 0; HD_TRY(launch_gn_partial(a.out, a.B, HW, C, part, &s2, r.st)); }
+    HD_TRY(r.alloc((size_t)a.B * C, A));
+    HD_TRY(r.alloc((size_t)a.B * C, Bv));
+    *E = nullptr;
+    if (film_mode == 2) HD_TRY(r.alloc((size_t)a.B * C, E));
+    if (!r.dry)
+        HD_TRY(launch_gn_finalize(part, slots, a.B, HW, C, r.c->arch.groups, gamma, beta, r.film, r.film_bs, film_off, film_mode, *A,
+                                  *Bv, *E, r.st));
+    r.free(part);
+    return 0;
+}
+
+// ResnetBlock (src/hicdiff.py:185-197; SR3: src/hicdiff_sr3.py:246-251).  in1 != null: channel concat.
+static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, Act* out) {
+    const int H = in0.H, W = in0.W, C = w.cout;
+    const bool sr3 = r.c->arch.sr3;
+    Act h1, h2;
+    HD_TRY(r.act(H, W, C, &h1));
+    ConvArgs a;
+    a.in0 = in0.p; a.C0 = in0.C; a.in1 = in1 ? in1->p : nullptr; a.C1 = in1 ? in1->C : 0;
+    a.B = r.B; a.H = H; a.W = W; a.IH = H; a.IW = W; a.stride = 1; a.pad = 1; a.cw = w.c1; a.out = h1.p;
+    float *A1, *B1, *E1;
+    HD_TRY(conv_gn(r, a, C, w.g1, w.b1, sr3 ? 2 : 1, w.film_off, &A1, &B1, &E1));
+    HD_TRY(r.act(H, W, C, &h2));
+    ConvArgs b;
+    b.in0 = h1.p; b.C0 = C; b.B = r.B; b.H = H; b.W = W; b.IH = H; b.IW = W; b.stride = 1; b.pad = 1; b.cw = w.c2; b.out = h2.p;
+    b.in_mode = IN_AFFINE_SILU; b.inA = A1; b.inB = B1; b.inE = E1; b.in_bstride = C;
+    float *A2, *B2, *E2;
+    HD_TRY(conv_gn(r, b, C, w.g2, w.b2, 0, 0, &A2, &B2, &E2));
+    r.free(h1); r.free(A1); r.free(B1); r.free(E1);
+    HD_TRY(r.act(H, W, C, out));
+    if (w.has_res) {
+        ConvArgs s;
+        s.in0 = in0.p; s.C0 = in0.C; s.in1 = in1 ? in1->p : nullptr; s.C1 = in1 ? in1->C : 0;
+        s.B = r.B; s.H = H; s.W = W; s.IH = H; s.IW = W; s.stride = 1; s.pad = 0; s.cw = w.res; s.out = out->p;
+        s.ep = EP_RES_AFFINE_SILU; s.res = h2.p; s.resA = A2; s.resB = B2; s.res_bstride = C;
+        HD_TRY(run_conv(r, s));
+    } else if (!r.dry) {
+        HD_TRY(launch_affine_silu_add(h2.p, A2, B2, in0.p, out->p, r.B, H * W, C, r.st));
+    }
+    r.free(h2); r.free(A2); r.free(B2);
+    return 0;
+}
+
+// Residual(PreNorm(LinearAttention)) / Residual(PreNorm(Attention)), src/hicdiff.py:199-251.
+static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
+    const int H = x.H, W = x.W, C = x.C, HW = H * W, heads = 4;
+    const size_t P = x.pixels();
+    float* stats; HD_TRY(r.alloc(P * 2, &stats));
+    if (!r.dry) HD_TRY(launch_ln_stats(x.p, P, C, stats, r.st));
+    Act qkv; HD_TRY(r.act(H, W, 384, &qkv));
+    ConvArgs q;
+    q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = w.qkv; q.out = qkv.p;
+    q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
+    HD_TRY(run_conv(r, q));
+    r.free(stats);
+    Act att; HD_TRY(r.act(H, W, 128, &att));
+    if (w.linear) {
+        float* ctx; HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
+        if (!r.dry) {
+            HD_TRY(launch_linattn_context(qkv.p, r.B, HW, heads, ctx, r.st));
+            HD_TRY(launch_linattn_apply(qkv.p, ctx, r.B, HW, heads, att.p, r.st));
+        }
+        r.free(ctx);
+    } else if (!r.dry) {
+        HD_TRY(launch_attn_full(qkv.p, r.B, HW, heads, att.p, r.st));
+    }
+    r.free(qkv);
+    HD_TRY(r.act(H, W, C, out));
+    ConvArgs o;
+    o.in0 = att.p; o.C0 = 128; o.B = r.B; o.H = H; o.W = W; o.IH = H; o.IW = W; o.stride = 1; o.pad = 0; o.cw = w.out;
+    if (w.linear) {
+        Act y; HD_TRY(r.act(H, W, C, &y));
+        o.out = y.p;
+        HD_TRY(run_conv(r, o));
+        if (!r.dry) HD_TRY(launch_ln_residual(y.p, w.out_g, x.p, out->p, P, C, r.st));
+        r.free(y);
+    } else {
+        o.out = out->p; o.ep = EP_RES; o.alpha = 1.f; o.res = x.p;
+        HD_TRY(run_conv(r, o));
+    }
+    r.free(att);
+    return 0;
+}
+
+static int time_and_film(Run& r, const void* t, int t_kind, float tval, bool uniform, float** film_out) {
+    hd_ctx* c = r.c;
+    r.Bt = uniform ? 1 : r.B;
+    float *temb, *tact, *film;
+    HD_TRY(r.alloc((size_t)r.Bt * c->time_dim, &temb));
+    HD_TRY(r.alloc((size_t)r.Bt * c->time_dim, &tact));
+    HD_TRY(r.alloc((size_t)r.Bt * c->film_n, &film));
+    if (!r.dry) {
+        HD_TRY(launch_time_mlp(uniform ? nullptr : t, t_kind, tval, c->arch.sr3, r.Bt, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t,
+                               c->b3, temb, tact, r.st));
+        HD_TRY(launch_film(tact, r.Bt, c->time_dim, c->film_wt, c->film_b, c->film_n, film, r.st));
+    }
+    r.free(temb); r.free(tact);
+    r.film = film; r.film_bs = uniform ? 0 : c->film_n;
+    *film_out = film;
+    return 0;
+}
+
+static int unet_forward(Run& r, const float* x, const float* cond, float* eps) {
+    hd_ctx* c = r.c;
+    const int S = r.S, n = c->arch.n_mults;
+    Act h0; HD_TRY(r.act(S, S, c->arch.dim, &h0));
+    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, h0.p, r.B, S, 7, c->cin0, c->arch.dim, r.st));
+    HD_TRY(probe(r, "init_conv", h0));
+    std::vector<Act> skips;
+    Act cur = h0;
+    for (int i = 0; i < n; ++i) {
+        const StageW& s = c->downs[i];
+        Act a1, a2, a3, d;
+        HD_TRY(unet_resblock(r, s.r1, cur, nullptr, &a1));
+        if (cur.p != h0.p) r.free(cur);
+        skips.push_back(a1);
+        HD_TRY(probe(r, "downs." + std::to_string(i) + ".0", a1));
+        HD_TRY(unet_resblock(r, s.r2, a1, nullptr, &a2));
+        HD_TRY(unet_attention(r, s.attn, a2, &a3));
+        HD_TRY(probe(r, "downs." + std::to_string(i) + ".2", a3));
+        r.free(a2);
+        skips.push_back(a3);
+        ConvArgs k;
+        k.in0 = a3.p; k.C0 = a3.C; k.B = r.B; k.IH = a3.H; k.IW = a3.W; k.cw = s.resample;
+        if (s.last) { k.H = a3.H; k.W = a3.W; k.stride = 1; k.pad = 1; }
+        else { k.H = a3.H / 2; k.W = a3.W / 2; k.stride = 2; k.pad = 0; }
+        HD_TRY(r.act(k.H, k.W, s.cout, &d));
+        k.out = d.p;
+        HD_TRY(run_conv(r, k));
+        HD_TRY(probe(r, "downs." + std::to_string(i), d));
+        cur = d;
+    }
+    {
+        Act m1, m2, m3;
+        HD_TRY(unet_resblock(r, c->mid1, cur, nullptr, &m1)); r.free(cur);
+        HD_TRY(unet_attention(r, c->mid_attn, m1, &m2)); r.free(m1);
+        HD_TRY(probe(r, "mid_attn", m2));
+        HD_TRY(unet_resblock(r, c->mid2, m2, nullptr, &m3)); r.free(m2);
+        HD_TRY(probe(r, "mid", m3));
+        cur = m3;
+    }
+    for (int i = 0; i < n; ++i) {
+        const StageW& s = c->ups[i];
+        Act a1, a2, a3, u;
+        Act sk = skips.back(); skips.pop_back();
+        HD_TRY(unet_resblock(r, s.r1, cur, &sk, &a1)); r.free(cur); r.free(sk);
+        sk = skips.back(); skips.pop_back();
+        HD_TRY(unet_resblock(r, s.r2, a1, &sk, &a2)); r.free(a1); r.free(sk);
+        HD_TRY(unet_attention(r, s.attn, a2, &a3)); r.free(a2);
+        ConvArgs k;
+        k.in0 = a3.p; k.C0 = a3.C; k.B = r.B; k.IH = a3.H; k.IW = a3.W; k.cw = s.resample; k.stride = 1; k.pad = 1;
+        if (s.last) { k.H = a3.H; k.W = a3.W; } else { k.H = a3.H * 2; k.W = a3.W * 2; k.upsample = 1; }
+        HD_TRY(r.act(k.H, k.W, s.cin, &u));
+        k.out = u.p;
+        HD_TRY(run_conv(r, k));
+        r.free(a3);
+        HD_TRY(probe(r, "ups." + std::to_string(i), u));
+        cur = u;
+    }
+    Act f;
+    HD_TRY(unet_resblock(r, c->final_res, cur, &h0, &f));
+    r.free(cur); r.free(h0);
+    HD_TRY(probe(r, "final_res", f));
+    if (!r.dry) HD_TRY(launch_rowdot(f.p, c->final_w, c->final_b, eps, f.pixels(), f.C, r.st));
+    r.free(f);
+    return 0;
+}
+
+static int hicedrn_forward(Run& r, const float* x, const float* cond, float* eps) {
+    hd_ctx* c = r.c;
+    const int S = r.S, F = c->arch.dim;
+    const bool sr3 = c->arch.sr3;
+    Act head; HD_TRY(r.act(S, S, F, &head));
+    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, head.p, r.B, S, 3, c->cin0, F, r.st));
+    HD_TRY(probe(r, "head", head));
+    Act cur = head;
+    for (size_t i = 0; i < c->body.size(); ++i) {
+        const ResW& w = c->body[i];
+        Act h, nx;
+        HD_TRY(r.act(S, S, F, &h));
+        ConvArgs a;
+        a.in0 = cur.p; a.C0 = F; a.B = r.B; a.H = S; a.W = S; a.IH = S; a.IW = S; a.stride = 1; a.pad = 1; a.cw = w.c1; a.out = h.p;
+        a.ep_bstride = r.film_bs;
+        if (sr3) { a.ep = EP_ADD_SILU; a.epShift = r.film + w.film_off; }
+        else { a.ep = EP_FILM_SILU; a.epScale = r.film + w.film_off; a.epShift = r.film + w.film_off + F; }
+        HD_TRY(run_conv(r, a));
+        HD_TRY(r.act(S, S, F, &nx));
+        ConvArgs b;
+        b.in0 = h.p; b.C0 = F; b.B = r.B; b.H = S; b.W = S; b.IH = S; b.IW = S; b.stride = 1; b.pad = 1; b.cw = w.c1; b.out = nx.p;
+        b.ep = EP_RES; b.alpha = 0.1f; b.res = cur.p;
+        HD_TRY(run_conv(r, b));
+        r.free(h);
+        if (cur.p != head.p) r.free(cur);
+        cur = nx;
+        if (i == 0 || i + 1 == c->body.size()) HD_TRY(probe(r, "body." + std::to_string(i), nx));
+    }
+    Act y; HD_TRY(r.act(S, S, F, &y));
+    ConvArgs t;
+    t.in0 = cur.p; t.C0 = F; t.B = r.B; t.H = S; t.W = S; t.IH = S; t.IW = S; t.stride = 1; t.pad = 1; t.cw = c->body_tail; t.out = y.p;
+    t.ep = EP_RES; t.alpha = 1.f; t.res = head.p;
+    HD_TRY(run_conv(r, t));
+    if (cur.p != head.p) r.free(cur);
+    r.free(head);
+    ConvArgs o;
+    o.in0 = y.p; o.C0 = F; o.B = r.B; o.H = S; o.W = S; o.IH = S; o.IW = S; o.stride = 1; o.pad = 1; o.cw = c->tail; o.out = eps;
+    HD_TRY(run_conv(r, o));
+    r.free(y);
+    return 0;
+}
+
+static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float tval, bool uniform, const float* cond, float* eps,
+                   int B, int S, hipStream_t st, bool dry) {
+    if (B < 1 || S < 8) return fail(c, HD_EINVAL, "bad batch or tile size");
+    if (c->arch.kind == HD_ARCH_UNET) {
+        int div = 1; for (int i = 0; i + 1 < c->arch.n_mults; ++i) div *= 2;
+        if (S % div) return fail(c, HD_EINVAL, "tile size must be divisible by 2^(len(dim_mults)-1)");
+    }
+    if ((S * S) % 4) return fail(c, HD_EINVAL, "S*S must be a multiple of 4");
+    if (!dry && !c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
+    if (!dry && (c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
+    Run r{c, st, dry, B, S, B, nullptr, 0};
+    c->pool.reset(dry);
+    float* film = nullptr;
+    HD_TRY(time_and_film(r, t, t_kind, tval, uniform, &film));
+    int rc = c->arch.kind == HD_ARCH_UNET ? unet_forward(r, x, cond, eps) : hicedrn_forward(r, x, cond, eps);
+    r.free(film);
+    return rc;
+}
+
+// ---- C ABI -------------------------------------------------------------------------------------
+extern "C" {
+
+const char* hd_version(void) { return "hicdiff_hip 0.1 (gfx950, fp32 MFMA)"; }
+
+const char* hd_last_error(const hd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
+    if (!out || !a) return HD_EINVAL;
+    *out = nullptr;
+    if (a->channels != 1) { g_err = "only channels == 1 is supported"; return HD_EINVAL; }
+    if (a->kind == HD_ARCH_UNET) {
+        if (a->dim < 16 || a->dim % 16 || a->n_mults < 1 || a->n_mults > 8 || a->groups < 1 || a->dim % a->groups) {
+            g_err = "Unet: dim must be a multiple of 16 (and of groups), 1 <= len(dim_mults) <= 8"; return HD_EINVAL;
+        }
+        for (int i = 0; i < a->n_mults; ++i) if (a->mults[i] < 1) { g_err = "Unet: dim_mults must be positive"; return HD_EINVAL; }
+    } else if (a->kind == HD_ARCH_HICEDRN) {
+        if (a->dim < 16 || a->dim % 16 || a->number_resnet < 1) { g_err = "hicedrn: n_feat must be a multiple of 16"; return HD_EINVAL; }
+    } else { g_err = "unknown architecture kind"; return HD_EINVAL; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return HD_EHIP; }
+    hd_ctx* c = new hd_ctx();
+    c->arch = *a; c->device = device;
+    c->cin0 = a->self_condition ? 2 : 1;
+    c->time_in = a->dim; c->time_dim = a->dim * 4;
+    if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
+    else { c->first_ks = 3; c->first_cout = a->dim; c->film_n = a->number_resnet * (a->sr3 ? 1 : 2) * a->dim; }
+    *out = c;
+    return HD_OK;
+}
+
+void hd_destroy(hd_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    for (void* p : c->owned) hipFree(p);
+    if (c->pool.base) hipFree(c->pool.base);
+    if (c->eps_buf) hipFree(c->eps_buf);
+    delete c;
+}
+
+int hd_load_weights(hd_ctx* c, const hd_named_tensor* tensors, int n, void* stream) {
+    if (!c || !tensors) return HD_EINVAL;
+    Loader L{c, (hipStream_t)stream, {}};
+    for (int i = 0; i < n; ++i) L.map[tensors[i].name] = &tensors[i];
+    int rc = c->arch.kind == HD_ARCH_UNET ? load_unet(L) : load_hicedrn(L);
+    if (rc == 0) c->loaded = true;
+    return keep_err(c, rc);
+}
+
+int hd_workspace_bytes(const hd_ctx* cc, int B, int S, size_t* out) {
+    hd_ctx* c = const_cast<hd_ctx*>(cc);
+    if (!c || !out) return HD_EINVAL;
+    Pool saved = c->pool;
+    int rc = forward(c, nullptr, nullptr, HD_T_FLOAT32, 0.f, false, nullptr, nullptr, B, S, nullptr, true);
+    size_t high = c->pool.high;
+    c->pool = saved;
+    if (rc != 0) return keep_err(c, rc);
+    *out = high;
+    return HD_OK;
+}
+
+int hd_reserve(hd_ctx* c, int B, int S) {
+    if (!c) return HD_EINVAL;
+    size_t need = 0;
+    HD_TRY(hd_workspace_bytes(c, B, S, &need));
+    if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
+    if (need > c->pool.cap) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+        if (c->pool.base) hipFree(c->pool.base);
+        c->pool.base = nullptr; c->pool.cap = 0;
+        void* p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(workspace) failed");
+        c->pool.base = (char*)p; c->pool.cap = need;
+    }
+    const size_t en = (size_t)B * S * S;
+    if (en > c->eps_cap) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+        if (c->eps_buf) hipFree(c->eps_buf);
+        void* p = nullptr;
+        if (hipMalloc(&p, en * sizeof(float)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(eps) failed");
+        c->eps_buf = (float*)p; c->eps_cap = en;
+    }
+    c->resB = std::max(c->resB, B); c->resS = std::max(c->resS, S);
+    return HD_OK;
+}
+
+int hd_eps_forward(hd_ctx* c, const float* x, const void* t, int t_kind, const float* cond, float* eps, int B, int S, void* stream) {
+    if (!c || !x || !t || !eps) return HD_EINVAL;
+    return keep_err(c, forward(c, x, t, t_kind, 0.f, false, cond, eps, B, S, (hipStream_t)stream, false));
+}
+
+int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, const hd_ddpm_coef* k, float* x0_out, int B, int S,
+                 uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
+    if (!c || !x || !k) return HD_EINVAL;
+    if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
+    hipStream_t st = (hipStream_t)stream;
+    HD_TRY(keep_err(c, forward(c, x, nullptr, HD_T_FLOAT32, k->time_value, true, cond, c->eps_buf, B, S, st, false)));
+    return keep_err(c, launch_ddpm_update(x, c->eps_buf, noise, k->sqrt_recip_alphas_cumprod, k->sqrt_recipm1_alphas_cumprod,
+                                          k->posterior_mean_coef1, k->posterior_mean_coef2, k->sigma, x0_out, B, S, seed, tile_offset,
+                                          step, st));
+}
+
+int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_ddrm_coef* k, float* x0_out, int B, int S,
+                 uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
+    if (!c || !x || !y || !k) return HD_EINVAL;
+    if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
+    hipStream_t st = (hipStream_t)stream;
+    HD_TRY(keep_err(c, forward(c, x, nullptr, HD_T_FLOAT32, k->time_value, true, nullptr, c->eps_buf, B, S, st, false)));
+    return keep_err(c, launch_ddrm_update(x, c->eps_buf, y, z, k->sqrt_at, k->sqrt_1m_at, k->sqrt_at_next, k->sigma_next, k->sigma_0,
+                                          k->etaA, k->etaB, k->etaC, x0_out, B, S, seed, tile_offset, step, st));
+}
+
+int hd_q_sample(hd_ctx* c, const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S, void* stream) {
+    if (!c || !x0 || !noise || !a || !s || !out) return HD_EINVAL;
+    return keep_err(c, launch_q_sample(x0, noise, a, s, out, B, S, (hipStream_t)stream));
+}
+
+int hd_loss_per_sample(hd_ctx* c, const float* pred, const float* target, int l2, float* out, int B, int S, void* stream) {
+    if (!c || !pred || !target || !out) return HD_EINVAL;
+    return keep_err(c, launch_loss(pred, target, l2, out, B, S, (hipStream_t)stream));
+}
+
+int hd_randn(hd_ctx* c, float* out, int B, int S, uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
+    if (!c || !out) return HD_EINVAL;
+    if ((S * S) % 4) return fail(c, HD_EINVAL, "S*S must be a multiple of 4");
+    return keep_err(c, launch_randn(out, B, S, seed, tile_offset, step, (hipStream_t)stream));
+}
+
+// ---- test-only entry points (include/hicdiff_hip_debug.h) ----
+int hd_debug_capture(hd_ctx* c, int enable) {
+    if (!c) return HD_EINVAL;
+    c->capture = enable != 0;
+    if (!enable) { for (auto& kv : c->captured) (void)hipFree(kv.second.p); c->captured.clear(); }
+    return HD_OK;
+}
+
+int hd_debug_read(hd_ctx* c, const char* label, float* dst, size_t n, int32_t dims[4]) {
+    if (!c || !label || !dims) return HD_EINVAL;
+    auto it = c->captured.find(label);
+    if (it == c->captured.end()) return fail(c, HD_EINVAL, std::string("no capture named '") + label + "'");
+    const Act& a = it->second;
+    dims[0] = a.B; dims[1] = a.H; dims[2] = a.W; dims[3] = a.C;
+    if (dst) {
+        if (n < a.numel()) return fail(c, HD_EINVAL, "capture buffer too small");
+        if (hipMemcpy(dst, a.p, a.numel() * sizeof(float), hipMemcpyDeviceToDevice) != hipSuccess) return fail(c, HD_EHIP, "capture read failed");
+    }
+    return HD_OK;
+}
+
+int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int IH, int IW, const float* w, const float* bias,
+                  int Cout, int K, int mode, const float* A, const float* Bv, const float* E, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const bool up = mode & 1, ws = mode & 2, unsh = mode & 4, aff = mode & 8, ln = mode & 16;
+    const int Cin = C0 + C1, KH = unsh ? 2 : K;
+    ConvW cw; cw.KH = cw.KW = KH; cw.Cin = Cin; cw.Cout = Cout; cw.CoutPad = (Cout + 63) / 64 * 64;
+    void *pw = nullptr, *pst = nullptr;
+    if (hipMalloc(&pw, (size_t)KH * KH * Cin * cw.CoutPad * sizeof(float)) != hipSuccess) return HD_EHIP;
+    cw.w = (float*)pw; cw.bias = const_cast<float*>(bias);
+    int rc = launch_pack_conv(w, cw.w, Cout, Cin, KH, KH, cw.CoutPad, ws, unsh, st);
+    ConvArgs a;
+    a.in0 = in0; a.C0 = C0; a.in1 = in1; a.C1 = C1; a.B = B; a.IH = IH; a.IW = IW; a.cw = cw; a.out = out;
+    if (unsh) { a.H = IH / 2; a.W = IW / 2; a.stride = 2; a.pad = 0; }
+    else if (up) { a.H = IH * 2; a.W = IW * 2; a.stride = 1; a.pad = K / 2; a.upsample = 1; }
+    else { a.H = IH; a.W = IW; a.stride = 1; a.pad = K / 2; }
+    if (aff) { a.in_mode = IN_AFFINE_SILU; a.inA = A; a.inB = Bv; a.inE = E; a.in_bstride = Cin; }
+    if (ln && rc == 0) {
+        if (hipMalloc(&pst, (size_t)B * IH * IW * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
+        rc = launch_ln_stats(in0, (size_t)B * IH * IW, C0, (float*)pst, st);
+        a.in_mode = IN_LAYERNORM; a.ln_stats = (float*)pst; a.ln_g = A;
+    }
+    if (rc == 0) rc = launch_conv(a, st, nullptr);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(pw); if (pst) (void)hipFree(pst);
+    return rc;
+}
+
+}  // extern "C"

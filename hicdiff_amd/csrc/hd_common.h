@@ -1,0 +1,105 @@
+// Shared declarations of the gfx950 HiCDiff engine (internal; the public surface is include/hicdiff_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+// Activations are NHWC fp32: [B][H][W][C].  The network's own input/output tiles have C == 1, so
+// the boundary's (B,1,S,S) tensors are this layout already.
+struct Act {
+    float* p = nullptr;
+    int B = 0, H = 0, W = 0, C = 0;
+    size_t numel() const { return (size_t)B * H * W * C; }
+    size_t pixels() const { return (size_t)B * H * W; }
+};
+
+// Packed convolution weight: [KH*KW][Cin][CoutPad] fp32 (CoutPad = Cout rounded up to 64, zero
+// filled), bias [Cout].  UNet 3x3 convs are weight-standardised at pack time.
+struct ConvW {
+    float* w = nullptr;
+    float* bias = nullptr;
+    int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0;
+};
+
+enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2 };
+enum EpFlags {
+    EP_FILM_SILU = 1,      // v = silu(v * (scale[b][n] + 1) + shift[b][n])       (hicedrn block, first conv)
+    EP_ADD_SILU = 2,       // v = silu(v + shift[b][n])                            (hicedrn SR3 block)
+    EP_RES = 4,            // v = alpha * v + res[pix][n]
+    EP_RES_AFFINE_SILU = 8 // v = v + silu(res[pix][n] * resA[b][n] + resB[b][n]) (UNet block tail through res_conv)
+};
+
+struct ConvArgs {
+    // input (optionally the channel concat of two tensors, never materialised)
+    const float* in0 = nullptr; const float* in1 = nullptr;
+    int C0 = 0, C1 = 0;
+    int B = 0, H = 0, W = 0;      // output spatial size
+    int IH = 0, IW = 0;           // size of the stored input tensor(s)
+    int stride = 1, pad = 0, upsample = 0;
+    ConvW cw;
+    // transform applied while staging the input tile
+    int in_mode = IN_NONE;
+    const float* inA = nullptr; const float* inB = nullptr; const float* inE = nullptr;  // [Bs][Cin]
+    int in_bstride = 0;           // elements between samples in inA/inB/inE (0: broadcast one row)
+    const float* ln_stats = nullptr;  // [pixels][2] mean, rstd
+    const float* ln_g = nullptr;      // [Cin]
+    // epilogue
+    int ep = 0;
+    const float* epScale = nullptr; const float* epShift = nullptr; int ep_bstride = 0;
+    float alpha = 1.f;
+    const float* res = nullptr; const float* resA = nullptr; const float* resB = nullptr; int res_bstride = 0;
+    float* out = nullptr;
+    // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
+    // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
+    float* gn_part = nullptr;
+};
+
+#define HD_CHECK_HIP(expr)                                                                 \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            hd_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));               \
+            return -3;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+void hd_set_error(const std::string& msg);
+
+// ---- launchers (each only enqueues on `st`) ---------------------------------------------------
+int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
+int conv_gn_slots(int B, int H, int W, int Cout);  // slots per sample the fused GN partials would use (0: not fusable)
+
+int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
+                     int standardize, int unshuffle, hipStream_t st);
+int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st);
+
+int launch_conv_small_cin(const float* x, const float* cond, const float* w, const float* bias, float* out,
+                          int B, int S, int KS, int Cin, int Cout, hipStream_t st);
+int launch_rowdot(const float* x, const float* w, const float* bias, float* out, size_t P, int C, hipStream_t st);
+
+int launch_time_mlp(const void* t, int t_kind, float tval, int sr3, int Bt, int dim, int time_dim, const float* w1t,
+                    const float* b1, const float* w3t, const float* b3, float* temb, float* temb_act, hipStream_t st);
+int launch_film(const float* act, int Bt, int K, const float* wt, const float* bias, int N, float* out, hipStream_t st);
+
+int launch_gn_partial(const float* x, int B, int HW, int C, float* part, int* slots_out, hipStream_t st);
+int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma,
+                       const float* beta, const float* film, int film_bstride, int film_off, int film_mode,
+                       float* A, float* Bv, float* E, hipStream_t st);
+int launch_affine_silu_add(const float* h, const float* A, const float* Bv, const float* res, float* out,
+                           int B, int HW, int C, hipStream_t st);
+int launch_ln_stats(const float* x, size_t P, int C, float* stats, hipStream_t st);
+int launch_ln_residual(const float* y, const float* g, const float* res, float* out, size_t P, int C, hipStream_t st);
+int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* ctx, hipStream_t st);
+int launch_linattn_apply(const float* qkv, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st);
+int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
+
+int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,
+                       float coef2, float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off,
+                       uint32_t step, hipStream_t st);
+int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
+                       float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC,
+                       float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st);
+int launch_q_sample(const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S,
+                    hipStream_t st);
+int launch_loss(const float* pred, const float* target, int l2, float* out, int B, int S, hipStream_t st);
+int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st);

@@ -1,0 +1,35 @@
+"""hicedrn epsilon-network (32 residual blocks x 256 channels; the net train.py / inference.py
+instantiate): drop-in for ``src/model/hicedrn_Diff.py:210-289``."""
+from __future__ import annotations
+
+from .. import _lib as L
+from .._engine import EpsNetBase, build_param_tree
+from .._specs import hicedrn_specs
+
+n_feat = 256
+kernel_size = 3
+
+
+class hicedrn_Diff(EpsNetBase):
+    _SR3 = False
+
+    def __init__(self, channels=1, out_dim=None, number_resnet=32, self_condition=False,
+                 learned_sinusoidal_cond=False, learned_sinusoidal_dim=16):
+        super().__init__()
+        if learned_sinusoidal_cond:
+            raise NotImplementedError("learned sinusoidal embedding is asserted off by GaussianDiffusion (src/hicdiff.py:451)")
+        if channels != 1 or (out_dim not in (None, 1)):
+            raise NotImplementedError("Hi-C tiles have one channel")
+        self.channels = channels
+        self.self_condition = self_condition
+        self.number_resnet = number_resnet
+        self.random_or_learned_sinusoidal_cond = False
+        self.out_dim = 1
+        build_param_tree(self, hicedrn_specs(channels, number_resnet, self_condition, self._SR3, n_feat))
+
+    def _arch(self) -> L.HdArchDesc:
+        a = L.HdArchDesc()
+        a.kind, a.dim, a.n_mults = L.HD_ARCH_HICEDRN, n_feat, 0
+        a.channels, a.self_condition, a.sr3 = self.channels, int(self.self_condition), int(self._SR3)
+        a.groups, a.number_resnet = 1, self.number_resnet
+        return a

@@ -1,0 +1,31 @@
+/*
+ * hicdiff_hip_debug.h -- test-only entry points of libhicdiff_hip.so (not part of the drop-in
+ * boundary): run one convolution through the implicit-GEMM kernel, and capture intermediate
+ * activations of a forward pass, so tests/ can localise a parity failure to one kernel.
+ */
+#ifndef HICDIFF_HIP_DEBUG_H
+#define HICDIFF_HIP_DEBUG_H
+#include "hicdiff_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[B][H][W][Cout] = conv(T(in0 ++ in1), w) + bias with the same kernel the networks use.
+ *   in0/in1: NHWC device tensors (in1 may be NULL), stored size IH x IW; w: torch layout
+ *   [Cout][Cin][K][K] (for unshuffle: [Cout][4*Cin][1][1]); mode bits: 1 = nearest x2 upsample,
+ *   2 = weight-standardise, 4 = pixel-unshuffle 2x2 stride 2, 8 = affine+SiLU input transform with
+ *   A,Bv [B][Cin] (E optional), 16 = LayerNorm input transform (stats computed internally, g = A). */
+int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int IH, int IW, const float* w,
+                  const float* bias, int Cout, int K, int mode, const float* A, const float* Bv, const float* E,
+                  float* out, void* stream);
+
+/* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
+int hd_debug_capture(hd_ctx* ctx, int enable);
+/* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.
+ * Returns HD_EINVAL when the label was not captured. */
+int hd_debug_read(hd_ctx* ctx, const char* label, float* dst, size_t n, int32_t dims[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,104 @@
+"""Kernel-level parity on the GPU: the implicit-GEMM convolution (every loader / geometry mode the
+networks use) against torch CPU fp32 conv2d, through the test-only C entry point hd_debug_conv."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from _util import rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5   # exact-fp32 MFMA path; differences are summation order only
+
+
+def _lib():
+    from hicdiff_amd import _lib as L
+    lib = L.load()
+    lib.hd_debug_conv.restype = C.c_int
+    lib.hd_debug_conv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def run_conv(x0, x1, w, bias, K, mode, A=None, Bv=None, E=None, out_hw=None):
+    lib = _lib()
+    dev = "cuda"
+    B, C0, IH, IW = x0.shape
+    C1 = 0 if x1 is None else x1.shape[1]
+    Cout = w.shape[0]
+    H, W = out_hw or (IH, IW)
+    d = lambda t: None if t is None else t.to(dev).contiguous()
+    x0d, x1d = d(nhwc(x0)), (None if x1 is None else d(nhwc(x1)))
+    wd, bd, Ad, Bd, Ed = d(w), d(bias), d(A), d(Bv), d(E)
+    out = torch.full((B, H, W, Cout), float("nan"), device=dev)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    rc = lib.hd_debug_conv(p(x0d), C0, p(x1d), C1, B, IH, IW, p(wd), p(bd), Cout, K, mode, p(Ad), p(Bd), p(Ed), p(out),
+                           C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).cpu()
+
+
+def rnd(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("B,S,Cin,Cout", [(2, 16, 64, 64), (1, 64, 16, 128), (3, 10, 32, 16), (7, 5, 64, 64), (3, 8, 48, 192),
+                                          (2, 40, 16, 64), (5, 20, 32, 1), (1, 32, 128, 256)])
+def test_conv3x3_plain(B, S, Cin, Cout):
+    x, w, b = rnd(1, B, Cin, S, S), rnd(2, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(3, Cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 0)) < TOL
+
+
+def test_conv3x3_concat_two_sources():
+    x0, x1 = rnd(1, 2, 32, 40, 40), rnd(2, 2, 16, 40, 40)
+    w, b = rnd(3, 128, 48, 3, 3) / 20, rnd(4, 128)
+    ref = F.conv2d(torch.cat((x0, x1), 1), w, b, padding=1)
+    assert rel_err(ref, run_conv(x0, x1, w, b, 3, 0)) < TOL
+
+
+def test_conv3x3_weight_standardised():
+    x, w, b = rnd(1, 3, 16, 10, 10), rnd(2, 16, 16, 3, 3) * 0.3 + 0.1, rnd(3, 16)
+    mean = w.mean(dim=(1, 2, 3), keepdim=True)
+    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    ref = F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 2)) < TOL
+
+
+def test_conv3x3_nearest_upsample_on_load():
+    x, w, b = rnd(1, 2, 32, 8, 8), rnd(2, 16, 32, 3, 3) / 17, rnd(3, 16)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 1, out_hw=(16, 16))) < TOL
+
+
+@pytest.mark.parametrize("S", [16, 40])
+def test_pixel_unshuffle_downsample(S):
+    C_, Cout = 16, 32
+    x, w, b = rnd(1, 2, C_, S, S), rnd(2, Cout, 4 * C_, 1, 1) / 8, rnd(3, Cout)
+    y = x.reshape(2, C_, S // 2, 2, S // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(2, 4 * C_, S // 2, S // 2)
+    ref = F.conv2d(y, w, b)
+    assert rel_err(ref, run_conv(x, None, w, b, 1, 4, out_hw=(S // 2, S // 2))) < TOL
+
+
+def test_conv1x1_layernorm_on_load():
+    x, w, g = rnd(1, 2, 64, 20, 20) * 2 + 0.5, rnd(2, 384, 64, 1, 1) / 8, rnd(3, 64) * 0.2 + 1
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    mean = x.mean(dim=1, keepdim=True)
+    xn = (x - mean) * (var + 1e-5).rsqrt() * g.view(1, -1, 1, 1)
+    ref = F.conv2d(xn, w)
+    assert rel_err(ref, run_conv(x, None, w, None, 1, 16, A=g)) < TOL
+
+
+def test_conv3x3_affine_silu_on_load_keeps_zero_padding():
+    B, Cc, S = 3, 32, 16
+    x, w, b = rnd(1, B, Cc, S, S), rnd(2, 64, Cc, 3, 3) / 17, rnd(3, 64)
+    A, Bv, E = rnd(4, B, Cc) * 0.5 + 1, rnd(5, B, Cc), rnd(6, B, Cc)
+    t = F.silu(x * A[:, :, None, None] + Bv[:, :, None, None]) + E[:, :, None, None]
+    ref = F.conv2d(t, w, b, padding=1)   # padding is applied AFTER the transform
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 8, A=A, Bv=Bv, E=E)) < TOL
