@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised Hi-C tiles / second for a 1000-step reverse (ancestral DDPM) chain.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload unet64|unet40|hicedrn64|unet64cond]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch: the epsilon-network forward plus the fused
+posterior update for B tiles (one hd_ddpm_step call).  All steps of a chain cost the same, so
+tiles/s for a full chain = tiles per batch / (1000 * seconds per step).  Tiles shard across ranks
+with no data-path collective (weak scaling: B tiles per GPU); the one RCCL all-gather of the
+finished tiles is exercised after the timed region and reported separately.
+
+Inputs are synthetic and already resident in HBM when the timed region starts: x_T from the
+device Philox generator, random-init weights of the named architecture (seeded).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic work per tile-step, SURVEY.md section 8(d) (forward hooks on the reference modules):
+# every conv/linear reads its input once and writes its output once in fp32; weights once per batch-step.
+WORK = {
+    "unet64": dict(arch="unet", cond=False, S=64, B=256, flop=14.358e9, act_bytes=92.6e6, w_bytes=142.7e6),
+    "unet64cond": dict(arch="unet", cond=True, S=64, B=256, flop=14.384e9, act_bytes=92.6e6, w_bytes=142.8e6),
+    "unet40": dict(arch="unet", cond=False, S=40, B=64, flop=5.611e9, act_bytes=36.2e6, w_bytes=142.7e6),
+    "hicedrn64": dict(arch="hicedrn", cond=False, S=64, B=256, flop=314.143e9, act_bytes=553.7e6, w_bytes=150.3e6),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+T_CHAIN = 1000
+
+
+def build_model(w, device):
+    torch.manual_seed(1234)
+    if w["arch"] == "unet":
+        if w["cond"]:
+            from hicdiff_amd.hicdiff_condition import GaussianDiffusion, Unet
+            net = Unet(64, dim_mults=(1, 2, 4, 8), self_condition=True)
+        else:
+            from hicdiff_amd.hicdiff import GaussianDiffusion, Unet
+            net = Unet(64, dim_mults=(1, 2, 4, 8))
+    else:
+        from hicdiff_amd.hicdiff import GaussianDiffusion
+        from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
+        net = hicedrn_Diff()
+    net = net.to(device)
+    diff = GaussianDiffusion(net, image_size=w["S"], timesteps=T_CHAIN, loss_type="l2", beta_schedule="linear").to(device)
+    return net, diff
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample:
+    the same step (eps-net + posterior update) on a small batch of the same tile size."""
+    from oracle import diffusion as OD, nets as ON, weights as W
+    try:
+        cores = len(os.sched_getaffinity(0))       # the cores this job may use, not the host's total
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("HICDIFF_CPU_THREADS", "16"))))   # GPU-box share: 16 cores per GPU
+    torch.set_num_threads(cores)
+    if w["arch"] == "unet":
+        cfg = ON.UnetCfg(self_condition=w["cond"])
+        sd = W.fill_state_dict(W.unet_shapes(self_condition=w["cond"]))
+        bs = 8
+    else:
+        cfg = ON.HicedrnCfg()
+        sd = W.fill_state_dict(W.hicedrn_shapes())
+        bs = 1
+    model = ON.make_eps_fn(sd, cfg)
+    kind = "cond" if w["cond"] else "uncond"
+    ref = OD.DiffusionRef(model, image_size=w["S"], timesteps=T_CHAIN, beta_schedule="linear", loss_type="l2", kind=kind)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((bs, 1, w["S"], w["S"]), generator=g)
+    cond = torch.rand((bs, 1, w["S"], w["S"]), generator=g) * 2 - 1 if w["cond"] else None
+    z = torch.randn(x.shape, generator=g)
+    x, _, _ = ref.p_sample(x, T_CHAIN - 1, cond, z)        # warm-up step
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        x, _, _ = ref.p_sample(x, T_CHAIN - 2 - n, cond, z)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    sec_per_step = el / n
+    return {
+        "value": bs / (T_CHAIN * sec_per_step), "unit": "tiles/s", "cores": cores, "kind": "port",
+        "sample": f"{n} reverse steps (eps-net + posterior update) of the same {w['arch']} on {bs} tiles of "
+                  f"1x{w['S']}x{w['S']}, torch CPU fp32 oracle, {cores} threads; scaled to a {T_CHAIN}-step chain",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="unet64", choices=sorted(WORK))
+    ap.add_argument("--batch", type=int, default=None, help="tiles per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    w = dict(WORK[args.workload])
+    if args.batch:
+        w["B"] = args.batch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from hicdiff_amd import _lib as L
+    from hicdiff_amd.sharding import all_gather_tiles
+    lib = L.load()
+    net, diff = build_model(w, device)
+    B, S = w["B"], w["S"]
+    diff.tile_offset = rank * B                       # noise keyed by the GLOBAL tile index
+    img = diff._initial_noise((B, 1, S, S), device)
+    cond = (torch.rand((B, 1, S, S), device=device) * 2 - 1) if w["cond"] else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t = T_CHAIN - 1
+    for _ in range(args.warmup):
+        diff._step_inplace(img, t, cond)
+        t -= 1
+    barrier()
+    lib.hd_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        diff._step_inplace(img, t, cond)
+        t -= 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rows = (L.HdProfileRow * 2)()
+    lib.hd_profile_read(rows)
+    lib.hd_profile_enable(0)
+
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = el.item()
+    sec_per_step = elapsed / args.steps
+    value = (B * world) / (T_CHAIN * sec_per_step)
+
+    # the one collective of the path: gather every rank's finished tiles (rank-ordered)
+    gather_ms = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        full = all_gather_tiles(img, dist)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        assert full.shape[0] == B * world
+
+    if rank == 0:
+        dom = max(rows, key=lambda r: r.total_ms)
+        ach = dom.flops / (dom.total_ms * 1e-3) / 1e12 if dom.total_ms > 0 else 0.0
+        roofline = {
+            "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": dom.kernel.decode(), "launches": int(dom.launches),
+            "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
+            "conv_time_share": round(sum(r.total_ms for r in rows) * 1e-3 / elapsed, 4),
+            "whole_step": {
+                "flop_frac_of_f32_mfma_peak": round(w["flop"] * B / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "hbm_frac_algorithmic": round((w["act_bytes"] * B + w["w_bytes"]) / sec_per_step / 1e9 / PEAK_HBM_GBS, 4),
+            },
+        }
+        out = {
+            "metric": "denoised Hi-C tiles/sec (1000-step reverse)", "value": round(value, 4), "unit": "tiles/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
+                                   f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
+                       "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}"},
+            "roofline": roofline,
+        }
+        if gather_ms is not None:
+            out["all_gather_ms"] = round(gather_ms, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,11 @@ class HdDdrmCoef(C.Structure):
     ]
 
 
+class HdProfileRow(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("launches", C.c_longlong), ("total_ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
 _P = C.c_void_p
 # symbol -> (restype, argtypes); exactly the declarations of include/hicdiff_hip.h
 SYMBOLS = {
@@ -59,6 +64,8 @@ SYMBOLS = {
     "hd_ddrm_step": (C.c_int, [_P, _P, _P, _P, C.POINTER(HdDdrmCoef), _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "hd_q_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "hd_loss_per_sample": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
+    "hd_profile_enable": (C.c_int, [C.c_int]),
+    "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow)]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
 }
 
@@ -74,6 +81,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: the HiCDiff hot path has no CPU/PyTorch fallback. "
             "Build it with `make -C hicdiff_amd/csrc` (hipcc --offload-arch=gfx950).")
+    # torch ships its own libamdhip64; load it FIRST so this library binds to the same HIP runtime
+    # (streams and device pointers are shared with torch). Loading /opt/rocm's copy before torch
+    # leaves two runtimes in the process and hipSetDevice fails.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete

@@ -234,11 +234,39 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvKArgs p) {
 
 // ---- host side -----------------------------------------------------------------------------------
 
+// Optional per-launch timing of the convolution kernels with HIP events on the launch stream
+// (hd_profile_* in include/hicdiff_hip.h): bench.py's live roofline figure comes from here.
+#include <vector>
+struct ProfRec { int variant; double flops, bytes; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+void hd_prof_enable(bool on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = on;
+}
+// Sums per variant (0: BN=128 tile, 1: BN=64 tile). Synchronises on the recorded events.
+void hd_prof_collect(double ms[2], double flops[2], double bytes[2], long long launches[2]) {
+    for (int v = 0; v < 2; ++v) { ms[v] = flops[v] = bytes[v] = 0.0; launches[v] = 0; }
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            ms[r.variant] += t; flops[r.variant] += r.flops; bytes[r.variant] += r.bytes; launches[r.variant] += 1;
+        }
+    }
+}
+
 struct TileGeom { int TB, TH, TW; };
 
 // Pick the TB x TH x TW output window (<= BM pixels) that wastes the fewest MFMA rows, then the
 // fewest staged halo pixels.  Small feature maps take whole images (TB > 1).
+#include <map>
+#include <tuple>
 static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int stride, int max_px) {
+    static std::map<std::tuple<int, int, int, int, int, int, int, int>, TileGeom> cache;
+    const auto key = std::make_tuple(B, H, W, BM, KH, KW, stride, max_px);
+    auto hit = cache.find(key);
+    if (hit != cache.end()) return hit->second;
     TileGeom best{1, 1, 1};
     double best_score = -1.0;
     for (int tw = 1; tw <= W && tw <= BM; ++tw) {
@@ -255,6 +283,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
             if (score > best_score) { best_score = score; best = {tb, th, tw}; }
         }
     }
+    cache[key] = best;
     return best;
 }
 
@@ -274,7 +303,16 @@ static int launch_variant(ConvKArgs& k, hipStream_t st) {
     const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
     k.ntiles_n = k.CoutPad / BN;
     dim3 grid((unsigned)(mtiles * k.ntiles_n));
+    ProfRec rec{};
+    if (g_prof_on) {
+        rec.variant = TN == 2 ? 0 : 1;
+        rec.flops = 2.0 * k.B * k.H * k.W * (double)k.Cout * k.Cin * k.KH * k.KW;
+        rec.bytes = 4.0 * ((double)k.B * k.IH * k.IW * k.Cin + (double)k.B * k.H * k.W * k.Cout + (double)k.KH * k.KW * k.Cin * k.Cout);
+        (void)hipEventCreate(&rec.e0); (void)hipEventCreate(&rec.e1);
+        (void)hipEventRecord(rec.e0, st);
+    }
     hipLaunchKernelGGL((conv_igemm_f32_kernel<TM, TN, CK>), grid, dim3(256), lds, st, k);
+    if (g_prof_on) { (void)hipEventRecord(rec.e1, st); g_prof.push_back(rec); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hd_set_error(std::string("conv launch: ") + hipGetErrorString(e)); return -3; }
     return 0;

@@ -696,6 +696,17 @@ int hd_randn(hd_ctx* c, float* out, int B, int S, uint64_t seed, uint64_t tile_o
     return keep_err(c, launch_randn(out, B, S, seed, tile_offset, step, (hipStream_t)stream));
 }
 
+int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
+
+int hd_profile_read(hd_profile_row rows[2]) {
+    if (!rows) return HD_EINVAL;
+    double ms[2], fl[2], by[2]; long long n[2];
+    hd_prof_collect(ms, fl, by, n);
+    static const char* names[2] = {"conv_igemm_f32_kernel<2,2,16>", "conv_igemm_f32_kernel<2,1,16>"};
+    for (int v = 0; v < 2; ++v) { rows[v].kernel = names[v]; rows[v].launches = n[v]; rows[v].total_ms = ms[v]; rows[v].flops = fl[v]; rows[v].bytes = by[v]; }
+    return HD_OK;
+}
+
 // ---- test-only entry points (include/hicdiff_hip_debug.h) ----
 int hd_debug_capture(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;

@@ -65,6 +65,9 @@ struct ConvArgs {
 
 void hd_set_error(const std::string& msg);
 
+void hd_prof_enable(bool on);
+void hd_prof_collect(double ms[2], double flops[2], double bytes[2], long long launches[2]);
+
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
 int conv_gn_slots(int B, int H, int W, int Cout);  // slots per sample the fused GN partials would use (0: not fusable)

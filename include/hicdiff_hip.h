@@ -157,6 +157,24 @@ int hd_loss_per_sample(hd_ctx* ctx, const float* pred, const float* target, int 
 int hd_randn(hd_ctx* ctx, float* out, int B, int S, uint64_t seed, uint64_t tile_offset,
              uint32_t step, void* stream);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Per-launch HIP-event timing of the convolution kernels on their launch stream (process-wide;
+ * not for use under stream capture).  hd_profile_enable(1) clears and starts recording,
+ * hd_profile_read synchronises on the recorded events and returns, per kernel variant, the number
+ * of launches, their summed duration and their summed ALGORITHMIC flops / bytes (each conv reads
+ * its input once, writes its output once, reads its weights once). bench.py derives
+ * roofline.achieved from it. */
+typedef struct {
+    const char* kernel;
+    long long launches;
+    double total_ms;
+    double flops;
+    double bytes;
+} hd_profile_row;
+int hd_profile_enable(int enable);
+int hd_profile_read(hd_profile_row rows[2]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,170 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared symbol,
+the mirror classes reproduce the reference's state-dict layout and schedule buffers, the product
+path refuses to run without a device, and the tile sharding / all-gather logic (world_size-2 gloo)."""
+import json
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from _util import GOLDEN, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for hdr in ("hicdiff_hip.h", "hicdiff_hip_debug.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(hd_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    import ctypes
+    from hicdiff_amd import _lib
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+    assert set(_lib.SYMBOLS) <= declared
+    assert b"gfx950" in ctypes.c_char_p(lib.hd_version()).value
+
+
+def test_create_validates_architecture_without_a_gpu_call():
+    import ctypes as C
+    from hicdiff_amd import _lib
+    lib = _lib.load()
+    bad = _lib.HdArchDesc()
+    bad.kind, bad.dim, bad.n_mults, bad.channels, bad.groups = _lib.HD_ARCH_UNET, 20, 2, 1, 8
+    ctx = C.c_void_p()
+    assert lib.hd_create(C.byref(ctx), 0, C.byref(bad)) == _lib.HD_EINVAL   # dim % 16
+    assert b"multiple of 16" in lib.hd_last_error(None)
+    bad.dim, bad.channels = 64, 3
+    assert lib.hd_create(C.byref(ctx), 0, C.byref(bad)) == _lib.HD_EINVAL
+
+
+def test_missing_library_is_a_loud_failure(tmp_path, monkeypatch):
+    from hicdiff_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+def test_state_dict_layout_matches_reference_checkpoints():
+    import hicdiff_amd.hicdiff as h0
+    import hicdiff_amd.hicdiff_condition as h1
+    import hicdiff_amd.hicdiff_sr3 as h2
+    from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
+    from hicdiff_amd.model.hicedrn_sr3_Diff import hicedrn_Diff as hicedrn_sr3
+    inv = json.load(open(os.path.join(GOLDEN, "param_inventory.json")))
+    cases = {
+        "unet_uncond": h0.Unet(64), "unet_cond": h1.Unet(64), "unet_sr3": h2.Unet(64, noise_level_emb=True),
+        "hicedrn_uncond": hicedrn_Diff(), "hicedrn_cond": hicedrn_Diff(self_condition=True),
+        "hicedrn_sr3": hicedrn_sr3(self_condition=True),
+    }
+    for name, m in cases.items():
+        assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [tuple(x) for x in map(tuple, inv[name])], name
+    d = h0.GaussianDiffusion(h0.Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=10, beta_schedule="linear")
+    keys = list(d.state_dict())
+    assert [k for k in keys if not k.startswith("model.")] == [k for k, _ in inv["diffusion_buffers"]]
+    assert sum(k.startswith("model.") for k in keys) == len(h0.Unet(16, dim_mults=(1, 2)).state_dict())
+    # a reference checkpoint (flat, 'model.'-prefixed keys) loads strictly
+    d2 = h0.GaussianDiffusion(h0.Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=10, beta_schedule="linear")
+    d2.load_state_dict(d.state_dict(), strict=True)
+
+
+@pytest.mark.parametrize("sched,T", [("linear", 50), ("linear", 1000), ("sigmoid", 2000), ("cosine", 1000)])
+def test_schedule_buffers_bit_exact_in_product(sched, T):
+    import hicdiff_amd.hicdiff as h0
+    g = golden("schedules")
+    d = h0.GaussianDiffusion(h0.Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=T, beta_schedule=sched)
+    for name, buf in d.named_buffers():
+        assert torch.equal(g[f"{sched}_{T}_{name}"], buf), name
+    import hicdiff_amd.hicdiff_sr3 as h2
+    d = h2.GaussianDiffusion(h2.Unet(16, dim_mults=(1, 2), noise_level_emb=True), image_size=16, timesteps=2000)
+    assert torch.equal(d.sqrt_alphas_cumprod_prev, g["linear_2000_sqrt_alphas_cumprod_prev"])
+
+
+def test_reference_guards_are_kept():
+    import hicdiff_amd.hicdiff as h0
+    net = h0.Unet(16, dim_mults=(1, 2))
+    with pytest.raises(ValueError):
+        h0.GaussianDiffusion(net, image_size=16, beta_schedule="quadratic")
+    with pytest.raises(AssertionError):
+        h0.GaussianDiffusion(net, image_size=16, objective="pred_eps")
+    with pytest.raises(AssertionError):
+        h0.GaussianDiffusion(net, image_size=16, timesteps=10, sampling_timesteps=20, beta_schedule="linear")
+    with pytest.raises(NotImplementedError):
+        h0.Unet(16, learned_sinusoidal_cond=True)
+    d = h0.GaussianDiffusion(net, image_size=16, timesteps=100, sampling_timesteps=10, beta_schedule="linear")
+    assert d.is_ddim_sampling and d.num_timesteps == 100
+
+
+def test_product_path_refuses_cpu_tensors():
+    import hicdiff_amd.hicdiff as h0
+    net = h0.Unet(16, dim_mults=(1, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))
+    from hicdiff_amd.functions.H_func import MakeFunc
+    with pytest.raises(NotImplementedError):
+        MakeFunc("sr4", 1, 16)
+    H = MakeFunc("deno", 1, 4)
+    v = torch.arange(32.).reshape(2, 1, 4, 4)
+    assert torch.equal(H.H(v), v.reshape(2, -1)) and torch.equal(H.H_pinv(v), v.reshape(2, -1))
+
+
+def test_shard_ranges_cover_all_tiles():
+    from hicdiff_amd.sharding import shard_range
+    for n in (0, 1, 7, 8, 255, 256, 257):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - s for s, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from hicdiff_amd.sharding import sample_sharded, all_gather_tiles
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+n, S = 7, 4
+def run_local(start, count):   # stand-in for a per-rank sampling loop keyed by the global tile index
+    idx = torch.arange(start, start + count, dtype=torch.float32).view(-1, 1, 1, 1)
+    return idx * torch.ones(count, 1, S, S) + 0.5
+full = sample_sharded(run_local, n, dist)
+want = run_local(0, n)
+assert torch.equal(full, want), (full[:, 0, 0, 0], want[:, 0, 0, 0])
+even = all_gather_tiles(run_local(dist.get_rank() * 3, 3), dist)
+assert torch.equal(even, run_local(0, 3 * dist.get_world_size()))
+t = torch.tensor([float(dist.get_rank() + 1)], dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)      # bench.py's max-over-ranks timing reduction
+assert t.item() == dist.get_world_size()
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_sharded_sampling_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+        assert b"ok" in out

@@ -1,0 +1,148 @@
+"""The oracle (oracle/) against every golden vector generated from the reference (CPU, no GPU).
+
+This is the oracle's pin: the fixtures were produced by importing the reference implementation
+(tests/golden/make_golden.py); the oracle must reproduce them before any HIP result is trusted.
+Schedules are compared bit for bit; network outputs to 2e-5 relative (they agreed exactly in the
+generating container; the slack only covers a different BLAS thread count on another host)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _util import GOLDEN, golden, oracle_hicedrn, oracle_unet, rel_err
+from oracle import ddrm as ODR
+from oracle import diffusion as OD
+from oracle import weights as W
+
+TOL = 2e-5
+CHAIN_TOL = 5e-4
+
+
+def test_parameter_inventories_match_reference_state_dicts():
+    inv = json.load(open(os.path.join(GOLDEN, "param_inventory.json")))
+    for kind in ("uncond", "cond", "sr3"):
+        mine = W.unet_shapes(self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+        assert [(k, list(s)) for k, s in mine.items()] == [tuple(x) for x in map(tuple, inv["unet_" + kind])]
+        mine = W.hicedrn_shapes(self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+        assert [(k, list(s)) for k, s in mine.items()] == [tuple(x) for x in map(tuple, inv["hicedrn_" + kind])]
+    assert [k for k, _ in inv["diffusion_buffers"]] == list(OD.BUFFER_NAMES)
+
+
+def test_closed_form_fill_is_a_pure_function():
+    a = W.fill_tensor("downs.0.0.block1.proj.weight", (64, 64, 3, 3))
+    b = W.fill_tensor("downs.0.0.block1.proj.weight", (64, 64, 3, 3))
+    assert torch.equal(a, b) and abs(a.std().item() - (1 / 576) ** 0.5) < 2e-3
+    assert abs(W.fill_tensor("x.norm.weight", (64,)).mean().item() - 1.0) < 0.1
+    assert not torch.equal(a, W.fill_tensor("downs.0.1.block1.proj.weight", (64, 64, 3, 3)))
+
+
+@pytest.mark.parametrize("sched,T", [("linear", 50), ("linear", 1000), ("linear", 2000), ("sigmoid", 1000), ("sigmoid", 2000),
+                                     ("cosine", 1000)])
+def test_schedule_buffers_bit_exact(sched, T):
+    g = golden("schedules")
+    mine = OD.diffusion_buffers(sched, T)
+    for name in OD.BUFFER_NAMES:
+        assert torch.equal(g[f"{sched}_{T}_{name}"], mine[name]), name
+
+
+def test_sr3_table_and_ddrm_betas_bit_exact():
+    g = golden("schedules")
+    assert torch.equal(g["linear_2000_sqrt_alphas_cumprod_prev"], OD.diffusion_buffers("linear", 2000)["sqrt_alphas_cumprod_prev"])
+    assert torch.equal(g["ddrm_linear_betas"], ODR.ddrm_betas("linear"))
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
+@pytest.mark.parametrize("tag", ["s16", "s40"])
+def test_tiny_unet_eps(kind, tag):
+    g = golden("tiny")
+    pre = f"{kind}_{tag}_"
+    out = oracle_unet(kind, 16, (1, 2))(g[pre + "x"], g[pre + "t"], g.get(pre + "cond"))
+    assert rel_err(g[pre + "eps"], out) < TOL
+
+
+def test_tiny_unet_probes():
+    from oracle import nets as ON
+    g = golden("tiny")
+    cfg = ON.UnetCfg(dim=16, dim_mults=(1, 2))
+    sd = W.fill_state_dict(W.unet_shapes(dim=16, dim_mults=(1, 2)))
+    probes = {}
+    with torch.no_grad():
+        ON.unet_eps(sd, g["uncond_s16_x"], g["uncond_s16_t"], None, cfg, probes)
+    for k in ("init_conv", "time_mlp", "downs.0", "mid", "ups.0"):
+        assert rel_err(g["uncond_s16_probe_" + k], probes[k]) < TOL, k
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
+def test_full_unet_eps(kind):
+    g = golden("eps")
+    m = oracle_unet(kind)
+    for tag in ("s40", "s64"):
+        pre = f"unet_{kind}_{tag}_"
+        assert rel_err(g[pre + "eps"], m(g[pre + "x"], g[pre + "t"], g.get(pre + "cond"))) < TOL
+    if kind == "uncond":
+        assert rel_err(g["unet_uncond_floatt_eps"], m(g["unet_uncond_floatt_x"], g["unet_uncond_floatt_t"])) < TOL
+
+
+@pytest.mark.parametrize("kind,nres,s", [("uncond", 3, 64), ("cond", 3, 64), ("sr3", 3, 40), ("uncond", 32, 40)])
+def test_hicedrn_eps(kind, nres, s):
+    g = golden("eps")
+    pre = f"hicedrn_{kind}_n{nres}_s{s}_"
+    out = oracle_hicedrn(kind, nres)(g[pre + "x"], g[pre + "t"], g.get(pre + "cond"))
+    assert rel_err(g[pre + "eps"], out) < TOL
+
+
+def test_ancestral_chains():
+    g = golden("trajectories")
+    ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=40, timesteps=50, beta_schedule="linear", loss_type="l2")
+    _, kept = ref.p_sample_loop((2, 1, 40, 40), OD.TorchNoise(1234), keep_every=10)
+    assert torch.equal(kept[50], g["uncond_xT"])
+    for t in range(0, 50, 10):
+        assert rel_err(g[f"uncond_x_after_t{t}"], kept[t]) < CHAIN_TOL
+    for kind, seed in (("cond", 4321), ("sr3", 999)):
+        ref = OD.DiffusionRef(oracle_unet(kind), image_size=40, timesteps=50, beta_schedule="linear", loss_type="l2", kind=kind)
+        _, kept = ref.p_sample_loop(g["cond_lq"], OD.TorchNoise(seed), keep_every=10)
+        for t in range(0, 50, 10):
+            assert rel_err(g[f"{kind}_x_after_t{t}"], kept[t]) < CHAIN_TOL
+
+
+def test_ddim():
+    g = golden("trajectories")
+    for eta in (0.0, 0.5):
+        ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=40, timesteps=1000, beta_schedule="sigmoid",
+                              sampling_timesteps=20, ddim_sampling_eta=eta)
+        assert rel_err(g[f"ddim_eta{eta}_x0"], ref.ddim_sample((2, 1, 40, 40), OD.TorchNoise(55))) < CHAIN_TOL
+
+
+@pytest.mark.parametrize("net", ["unet", "hicedrn3"])
+def test_ddrm_chains(net):
+    g = golden("trajectories")
+    model = oracle_unet("uncond") if net == "unet" else oracle_hicedrn("uncond", 3)
+    betas = ODR.ddrm_betas("linear")
+    for sigma_0 in (0.1, 1.0):
+        pre = f"ddrm_{net}_s{sigma_0}_"
+        nz = OD.TorchNoise(2024)
+        x = nz.randn((2, 1, 40, 40))
+        out, x0, kept = ODR.ddrm_denoise(x, range(0, 1000, 20), model, betas, g[pre + "y0"], sigma_0, noise=nz, keep_steps=(10, 25, 40))
+        for k in (10, 25, 40):
+            assert rel_err(g[pre + f"x_step{k}"], kept[k]) < CHAIN_TOL
+        assert rel_err(g[pre + "final"], out) < CHAIN_TOL
+        assert rel_err(g[pre + "x0_last"], x0) < CHAIN_TOL
+
+
+def test_losses_and_q_sample():
+    g = golden("losses")
+    for loss in ("l1", "l2"):
+        ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=40, timesteps=1000, beta_schedule="sigmoid", loss_type=loss)
+        val = ref.p_losses(g["x0"], g[f"uncond_{loss}_t"], g[f"uncond_{loss}_eps"])
+        assert abs(val.item() - g[f"uncond_{loss}_loss"].item()) < 1e-5 * abs(val.item())
+    ref = OD.DiffusionRef(oracle_unet("cond"), image_size=40, timesteps=1000, beta_schedule="linear", loss_type="l2", kind="cond")
+    val = ref.p_losses(g["x0"], g["cond_l2_t"], g["cond_l2_eps"], g["lq"])
+    assert abs(val.item() - g["cond_l2_loss"].item()) < 1e-5 * abs(val.item())
+    ref = OD.DiffusionRef(oracle_unet("sr3"), image_size=40, timesteps=2000, beta_schedule="linear", loss_type="l2", kind="sr3")
+    assert torch.equal(ref.sr3_draw_level(np.random.RandomState(7), 4), g["sr3_l2_level"])
+    val = ref.p_losses_sr3(g["x0"], g["sr3_l2_level"], g["sr3_l2_eps"], g["lq"])
+    assert abs(val.item() - g["sr3_l2_loss"].item()) < 1e-5 * abs(val.item())
+    ref = OD.DiffusionRef(None, image_size=40, timesteps=1000, beta_schedule="sigmoid")
+    assert torch.equal(ref.q_sample(g["x0"], g["q_sample_t"], g["uncond_l2_eps"]), g["q_sample_out"])
