@@ -1,8 +1,4 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; tail -3 gpurun_out/smoke.log
-python bench.py --steps 5 --warmup 2 > gpurun_out/bench1.log 2>&1; tail -3 gpurun_out/bench1.log
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof1 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof1.log 2>&1
-tail -2 $GRAFT_REPO_ROOT/gpurun_out/prof1.log
-find $GRAFT_REPO_ROOT/gpurun_out/prof1 -name "*stats*" | head
+python -m pytest tests -m gpu -q 2>&1 | tail -8 > gpurun_out/p.log; cat gpurun_out/p.log
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/bench3.log 2>&1; tail -1 gpurun_out/bench3.log

@@ -255,6 +255,18 @@ class DiffusionCore(nn.Module):
     def ddim_sample(self, shape, return_all_timesteps=False):
         """src/hicdiff.py:622-664.  The epsilon-network runs on the HIP engine; the few per-step
         scalar-tensor updates are device elementwise ops."""
+        eng = self.model.engine(self._device())
+        saved = eng.precision
+        # Strided DDIM divides eps by sqrt(alpha_bar) at a few, far-apart steps with no noise to wash the
+        # difference out: a 2e-5 eps error can reach 1e-2 in x_0.  It runs 20-50x fewer network calls than
+        # the ancestral chain, so it takes the exact-fp32 convolutions and keeps the 1e-3 parity bound.
+        eng.set_precision(L.HD_PRECISION_F32)
+        try:
+            return self._ddim_sample(shape, return_all_timesteps)
+        finally:
+            eng.set_precision(saved)
+
+    def _ddim_sample(self, shape, return_all_timesteps=False):
         shape = tuple(shape)
         batch, device, T, S, eta = shape[0], self._device(), self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
         times = list(reversed(torch.linspace(-1, T - 1, steps=S + 1).int().tolist()))

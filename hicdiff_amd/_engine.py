@@ -45,6 +45,8 @@ class Engine:
             raise L.HdError(rc, (self.lib.hd_last_error(None) or b"").decode())
         self._sig = None
         self._reserved = (0, 0)
+        import os
+        self.precision = L.HD_PRECISION_F32 if os.environ.get("HICDIFF_PRECISION", "") == "f32" else L.HD_PRECISION_BF16X3
 
     def __del__(self):
         try:
@@ -88,6 +90,11 @@ class Engine:
         B2, S2 = max(B, self._reserved[0]), max(S, self._reserved[1])
         self._check(self.lib.hd_reserve(self.ctx, B2, S2))
         self._reserved = (B2, S2)
+
+    def set_precision(self, mode: int):
+        """L.HD_PRECISION_F32 (exact fp32 MFMA) or L.HD_PRECISION_BF16X3 (default, split-bf16 x3)."""
+        self._check(self.lib.hd_set_precision(self.ctx, int(mode)))
+        self.precision = int(mode)
 
     def workspace_bytes(self, B: int, S: int) -> int:
         out = C.c_size_t()

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(_HERE, "libhicdiff_hip.so")
 HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -4, -5
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
+HD_PRECISION_F32, HD_PRECISION_BF16X3 = 0, 1
+HD_PROFILE_ROWS = 5
 
 
 class HdArchDesc(C.Structure):
@@ -66,6 +68,7 @@ SYMBOLS = {
     "hd_loss_per_sample": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
     "hd_profile_enable": (C.c_int, [C.c_int]),
     "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow)]),
+    "hd_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
 }
 

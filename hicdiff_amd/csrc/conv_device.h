@@ -1,0 +1,170 @@
+// Device-side pieces shared by the two implicit-GEMM convolution kernels (conv_f32.hip: exact fp32
+// MFMA; conv_bf16x3.hip: split-bf16 x3 MFMA): launch arguments, tile decoding, the staged-pixel
+// tables, the loader transform and the epilogue.
+#pragma once
+#include "hd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKArgs {
+    const float* in0; const float* in1;
+    int C0, C1, Cin;
+    int B, H, W, IH, IW, stride, pad, upsample, KH, KW;
+    const float* w; const unsigned short* wsplit; const float* bias;
+    int Cout, CoutPad;
+    int TB, TH, TW, LH, LW, npx, tiles_x, tiles_y, ntiles_n;
+    int in_mode; const float* inA; const float* inB; const float* inE; int in_bstride;
+    const float* ln_stats; const float* ln_g;
+    int ep; const float* epScale; const float* epShift; int ep_bstride;
+    float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
+    float* out; float* gn_part; int gn_slots;
+};
+
+// x * sigmoid(x) with the hardware exp2 / reciprocal (relative error ~1e-7)
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
+
+struct TileCtx {
+    int tid, lane, wm, wn, half, l31;
+    int tile_x, tile_y, b0, y0, x0, n0;
+    int thw, mvalid;
+};
+
+// 4 waves arranged WM x WN; wave (wm, wn) owns rows [wm*32*TM, +32*TM) and columns [wn*32*TN, +32*TN).
+template <int WN, int BN>
+__device__ __forceinline__ TileCtx tile_decode(const ConvKArgs& p) {
+    TileCtx t;
+    t.tid = threadIdx.x; t.lane = t.tid & 63;
+    const int wave = t.tid >> 6;
+    t.wm = wave / WN; t.wn = wave % WN; t.half = t.lane >> 5; t.l31 = t.lane & 31;
+    int bid = blockIdx.x;
+    const int nt = bid % p.ntiles_n;
+    int mt = bid / p.ntiles_n;
+    t.tile_x = mt % p.tiles_x; mt /= p.tiles_x;
+    t.tile_y = mt % p.tiles_y;
+    const int tile_b = mt / p.tiles_y;
+    t.b0 = tile_b * p.TB; t.y0 = t.tile_y * p.TH; t.x0 = t.tile_x * p.TW; t.n0 = nt * BN;
+    t.thw = p.TH * p.TW; t.mvalid = p.TB * t.thw;
+    return t;
+}
+
+// pxsrc[i]: linear index of the stored input pixel feeding staged pixel i (or -1: zero padding /
+// outside the batch); rowpix[m]: linear output pixel of GEMM row m (or -1).
+template <int BM>
+__device__ __forceinline__ void init_tables(const ConvKArgs& p, const TileCtx& t, int* pxsrc, int* pxb, int* rowpix, int* rowb) {
+    const int LH = p.LH, LW = p.LW;
+    for (int i = t.tid; i < p.npx; i += 256) {
+        int tb = i / (LH * LW);
+        int r = i - tb * LH * LW;
+        int ly = r / LW, lx = r - ly * LW;
+        int b = t.b0 + tb;
+        int iy = t.y0 * p.stride + ly - p.pad, ix = t.x0 * p.stride + lx - p.pad;
+        int src = -1;
+        if (b < p.B) {
+            if (p.upsample) {
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) src = (b * p.IH + (iy >> 1)) * p.IW + (ix >> 1);
+            } else if (iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
+                src = (b * p.IH + iy) * p.IW + ix;
+            }
+        }
+        pxsrc[i] = src;
+        pxb[i] = b < p.B ? b : p.B - 1;
+    }
+    for (int m = t.tid; m < BM; m += 256) {
+        int tb = m / t.thw;
+        int r = m - tb * t.thw;
+        int ty = r / p.TW, tx = r - ty * p.TW;
+        int b = t.b0 + tb, y = t.y0 + ty, x = t.x0 + tx;
+        bool v = (m < t.mvalid) && b < p.B && y < p.H && x < p.W;
+        rowpix[m] = v ? (b * p.H + y) * p.W + x : -1;
+        rowb[m] = b < p.B ? b : p.B - 1;
+    }
+}
+
+// staged-pixel offset of GEMM row (wm, tm, lane) inside the LDS window
+template <int TM>
+__device__ __forceinline__ int row_px_offset(const ConvKArgs& p, const TileCtx& t, int tm) {
+    int m = t.wm * 32 * TM + tm * 32 + t.l31;
+    if (m >= t.mvalid) m = 0;
+    int tb = m / t.thw;
+    int r = m - tb * t.thw;
+    int ty = r / p.TW, tx = r - ty * p.TW;
+    return (tb * p.LH + ty * p.stride) * p.LW + tx * p.stride;
+}
+
+// loader transform on 4 consecutive channels (starting at cc) of staged pixel s of sample b
+__device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int cc, int s, int b) {
+    if (p.in_mode == IN_AFFINE_SILU) {
+        const int o = b * p.in_bstride + cc;
+        const float4 A = *reinterpret_cast<const float4*>(p.inA + o);
+        const float4 Bv = *reinterpret_cast<const float4*>(p.inB + o);
+        v.x = silu_f(v.x * A.x + Bv.x); v.y = silu_f(v.y * A.y + Bv.y);
+        v.z = silu_f(v.z * A.z + Bv.z); v.w = silu_f(v.w * A.w + Bv.w);
+        if (p.inE) {
+            const float4 E = *reinterpret_cast<const float4*>(p.inE + o);
+            v.x += E.x; v.y += E.y; v.z += E.z; v.w += E.w;
+        }
+    } else if (p.in_mode == IN_LAYERNORM) {
+        const float mu = p.ln_stats[2 * (size_t)s], rs = p.ln_stats[2 * (size_t)s + 1];
+        const float4 g = *reinterpret_cast<const float4*>(p.ln_g + cc);
+        v.x = (v.x - mu) * rs * g.x; v.y = (v.y - mu) * rs * g.y;
+        v.z = (v.z - mu) * rs * g.z; v.w = (v.w - mu) * rs * g.w;
+    }
+    return v;
+}
+
+template <int TM, int TN, int WM>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
+                                              const int* rowb) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int n = t.n0 + t.wn * 32 * TN + tn * 32 + t.l31;
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = t.wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;
+                const int pix = rowpix[m];
+                if (pix < 0 || !nok) continue;
+                float v = acc[tm][tn][r] + bias;
+                s1 += v; s2 += v * v;
+                if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                    const int o = rowb[m] * p.ep_bstride + n;
+                    if (p.ep & EP_FILM_SILU) v = v * (p.epScale[o] + 1.f) + p.epShift[o];
+                    else v = v + p.epShift[o];
+                    v = silu_f(v);
+                }
+                if (p.ep & EP_RES) v = p.alpha * v + p.res[(size_t)pix * p.Cout + n];
+                if (p.ep & EP_RES_AFFINE_SILU) {
+                    const int o = rowb[m] * p.res_bstride + n;
+                    v += silu_f(p.res[(size_t)pix * p.Cout + n] * p.resA[o] + p.resB[o]);
+                }
+                p.out[(size_t)pix * p.Cout + n] = v;
+            }
+        }
+        if (p.gn_part) {  // TB == 1: every row of this workgroup belongs to sample b0
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (t.half == 0 && nok) {
+                const int slot = (t.tile_y * p.tiles_x + t.tile_x) * WM + t.wm;
+                float* d = p.gn_part + (((size_t)t.b0 * p.gn_slots + slot) * p.Cout + n) * 2;
+                d[0] = s1; d[1] = s2;
+            }
+        }
+    }
+}
+
+// host-side launch record shared by the two kernel files
+struct ConvLaunch {
+    ConvKArgs k;
+    size_t lds;
+    int variant;     // profiler row
+    int ck;          // K slice
+    int cfg;         // 0: 128 x 128 tile (waves 2 x 2), 1: 128 x 64 (2 x 2), 2: 256 x 64 (4 x 1)
+};
+int launch_conv_f32(ConvLaunch& L, hipStream_t st);
+int launch_conv_bf16x3(ConvLaunch& L, hipStream_t st);
+void conv_prof_begin(const ConvLaunch& L, hipStream_t st);
+void conv_prof_end(hipStream_t st);

@@ -1,0 +1,257 @@
+// Host side of the implicit-GEMM convolution: tile planning under an LDS budget, per-launch event
+// profiling, dispatch to the two arithmetic paths, and the weight packing kernels.
+//
+// One kernel family serves every "wide" convolution of the two epsilon-networks (reference call
+// sites: WeightStandardizedConv2d / Conv2d 3x3 src/hicdiff.py:75,158,320,336; 1x1 qkv / to_out /
+// res_conv :183,205,208,236,237; pixel-unshuffle Downsample :78-82 expressed as a 2x2 stride-2 conv;
+// hicedrn's 3x3 body src/model/hicedrn_Diff.py:169-208,256-262):
+//
+//   out[pix][n] = epilogue( bias[n] + sum_{tap,c} T(in)[pix (+) tap][c] * W[tap][c][n] )
+//
+//   * activations NHWC fp32; GEMM M = output pixels (a TB x TH x TW window per workgroup, so small
+//     feature maps fold several images into one tile), N = Cout, K = taps * Cin;
+//   * the input window (with halo) of one CK-channel slice is staged ONCE in LDS and re-used by all
+//     taps; T() is applied while staging: GroupNorm-apply + FiLM + SiLU of the producing conv
+//     (per-(sample,channel) affine A,B[,E]), channel LayerNorm, nearest x2 upsample (index math),
+//     channel concat of two tensors (two base pointers) -- none of these is ever materialised;
+//   * 4 waves, each TM x TN tiles of 32x32 accumulators; lanes of a 32x32 C tile hold one output
+//     channel each, so NHWC stores are 128-byte rows and GroupNorm per-channel partial sums fall out
+//     of the epilogue with one cross-half exchange.
+#include "conv_device.h"
+
+#include <map>
+#include <tuple>
+#include <vector>
+
+// ---- per-launch timing with HIP events on the launch stream (hd_profile_* in hicdiff_hip.h) ------
+struct ProfRec { int variant; double flops, bytes; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static ProfRec g_cur;
+void hd_prof_enable(bool on) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = on;
+}
+void hd_prof_collect(double* ms, double* flops, double* bytes, long long* launches) {
+    for (int v = 0; v < HD_PROF_VARIANTS; ++v) { ms[v] = flops[v] = bytes[v] = 0.0; launches[v] = 0; }
+    for (auto& r : g_prof) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
+            ms[r.variant] += t; flops[r.variant] += r.flops; bytes[r.variant] += r.bytes; launches[r.variant] += 1;
+        }
+    }
+}
+const char* hd_prof_variant_name(int v) {
+    static const char* names[HD_PROF_VARIANTS] = {
+        "conv_igemm_f32_kernel<2,2,16>", "conv_igemm_f32_kernel<2,1,16>",
+        "conv_igemm_bf16x3_kernel<128x128>", "conv_igemm_bf16x3_kernel<128x64>", "conv_igemm_bf16x3_kernel<256x64>"};
+    return names[v];
+}
+void conv_prof_begin(const ConvLaunch& L, hipStream_t st) {
+    if (!g_prof_on) return;
+    const ConvKArgs& k = L.k;
+    g_cur = ProfRec{};
+    g_cur.variant = L.variant;
+    g_cur.flops = 2.0 * k.B * k.H * k.W * (double)k.Cout * k.Cin * k.KH * k.KW;
+    g_cur.bytes = 4.0 * ((double)k.B * k.IH * k.IW * k.Cin + (double)k.B * k.H * k.W * k.Cout + (double)k.KH * k.KW * k.Cin * k.Cout);
+    (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
+    (void)hipEventRecord(g_cur.e0, st);
+}
+void conv_prof_end(hipStream_t st) {
+    if (!g_prof_on) return;
+    (void)hipEventRecord(g_cur.e1, st);
+    g_prof.push_back(g_cur);
+}
+
+// ---- tile planning ---------------------------------------------------------------------------------
+struct TileGeom { int TB, TH, TW; };
+
+// Pick the TB x TH x TW output window (<= BM pixels) that wastes the fewest MFMA rows, then the
+// fewest staged halo pixels.  Small feature maps take whole images (TB > 1).
+static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int stride, int max_px) {
+    static std::map<std::tuple<int, int, int, int, int, int, int, int>, TileGeom> cache;
+    const auto key = std::make_tuple(B, H, W, BM, KH, KW, stride, max_px);
+    auto hit = cache.find(key);
+    if (hit != cache.end()) return hit->second;
+    TileGeom best{1, 1, 1};
+    double best_score = -1.0;
+    for (int tw = 1; tw <= W && tw <= BM; ++tw) {
+        for (int th = 1; th <= H && th * tw <= BM; ++th) {
+            int tb = 1;
+            if (th == H && tw == W) { tb = BM / (H * W); if (tb > B) tb = B; if (tb < 1) tb = 1; }
+            long lh = (long)(th - 1) * stride + KH, lw = (long)(tw - 1) * stride + KW;
+            long npx = tb * lh * lw;
+            if (npx > max_px) continue;
+            long tiles = (long)((B + tb - 1) / tb) * ((H + th - 1) / th) * ((W + tw - 1) / tw);
+            double eff = (double)B * H * W / ((double)tiles * BM);
+            double halo = (double)npx / (double)(tb * th * tw * stride * stride);
+            double score = eff - 0.02 * halo;
+            if (score > best_score) { best_score = score; best = {tb, th, tw}; }
+        }
+    }
+    cache[key] = best;
+    return best;
+}
+
+// LDS plan of one launch: tile geometry under a per-workgroup LDS budget that keeps two workgroups
+// resident per CU (160 KiB LDS), and inside the register-prefetch capacity of the kernel variant.
+static const size_t LDS_BUDGET = 78 * 1024;
+struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, variant; size_t pitch, lds; };
+
+static ConvPlan plan_conv(const ConvArgs& a) {
+    ConvPlan pl{};
+    pl.fast = a.precision == HD_PREC_BF16X3 && a.cw.wsplit != nullptr;
+    pl.ck = pl.fast ? a.cw.ck : 16;
+    const bool wide = a.cw.CoutPad % 128 == 0;
+    pl.BN = wide ? 128 : 64;
+    pl.BM = 128; pl.WM = 2; pl.cfg = wide ? 0 : 1;
+    // 256 x 64 tile (waves 4 x 1) for 64-channel outputs on large feature maps.  The choice must not depend on
+    // the batch size: GroupNorm partial sums follow the tiling, and a tile's result has to be bit-identical
+    // whether it is sampled alone, in a batch of 256 or on another rank.
+    if (pl.fast && !wide && a.H * a.W >= 1024) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
+    pl.variant = pl.fast ? 2 + pl.cfg : pl.cfg;
+    pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
+    const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
+    long max_px = (long)((LDS_BUDGET - wbytes - 2 * pl.BM * 4) / (pl.pitch + 8));
+    if (pl.fast) {
+        const long maxi = pl.ck == 32 ? (pl.cfg == 2 ? 6 : 5) : 3;
+        max_px = std::min(max_px, 256 * maxi / (pl.ck / 8));
+    }
+    if (max_px > 512) max_px = 512;
+    pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
+    const int LH = (pl.g.TH - 1) * a.stride + a.cw.KH, LW = (pl.g.TW - 1) * a.stride + a.cw.KW;
+    const int npx = pl.g.TB * LH * LW, npx4 = (npx + 3) & ~3;
+    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + wbytes + (size_t)npx * pl.pitch;
+    return pl;
+}
+
+int conv_gn_slots(const ConvArgs& a) {
+    const ConvPlan pl = plan_conv(a);
+    if (pl.g.TB != 1) return 0;
+    return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW) * pl.WM;
+}
+
+int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
+    ConvLaunch L{};
+    ConvKArgs& k = L.k;
+    k.in0 = a.in0; k.in1 = a.in1; k.C0 = a.C0; k.C1 = a.C1; k.Cin = a.C0 + a.C1;
+    k.B = a.B; k.H = a.H; k.W = a.W; k.IH = a.IH; k.IW = a.IW;
+    k.stride = a.stride; k.pad = a.pad; k.upsample = a.upsample; k.KH = a.cw.KH; k.KW = a.cw.KW;
+    k.w = a.cw.w; k.wsplit = a.cw.wsplit; k.bias = a.cw.bias; k.Cout = a.cw.Cout; k.CoutPad = a.cw.CoutPad;
+    k.in_mode = a.in_mode; k.inA = a.inA; k.inB = a.inB; k.inE = a.inE; k.in_bstride = a.in_bstride;
+    k.ln_stats = a.ln_stats; k.ln_g = a.ln_g;
+    k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
+    k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
+    k.out = a.out;
+    const ConvPlan pl = plan_conv(a);
+    if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
+        hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");
+        return -1;
+    }
+    const TileGeom g = pl.g;
+    k.TB = g.TB; k.TH = g.TH; k.TW = g.TW;
+    k.LH = (g.TH - 1) * a.stride + k.KH; k.LW = (g.TW - 1) * a.stride + k.KW;
+    k.npx = g.TB * k.LH * k.LW;
+    k.tiles_y = (a.H + g.TH - 1) / g.TH; k.tiles_x = (a.W + g.TW - 1) / g.TW;
+    k.ntiles_n = k.CoutPad / pl.BN;
+    k.gn_part = nullptr; k.gn_slots = 0;
+    if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x * pl.WM; }
+    if (gn_slots_out) *gn_slots_out = k.gn_slots;
+    L.lds = pl.lds; L.variant = pl.variant; L.ck = pl.ck; L.cfg = pl.cfg;
+    if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }
+    return pl.fast ? launch_conv_bf16x3(L, st) : launch_conv_f32(L, st);
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+// src: torch layout [Cout][Cin][KH][KW]; dst: [KH*KW][Cin][CoutPad] (pad columns zeroed by the
+// caller's memset).  standardize: (w - mean_o) * rsqrt(var_o + 1e-5), biased variance over
+// (Cin,KH,KW), src/hicdiff.py:89-97.  unshuffle: src is the 1x1 weight [Cout][4*C] applied after
+// 'b c (h p1) (w p2) -> b (c p1 p2) h w' (src/hicdiff.py:80); it becomes a 2x2 stride-2 conv with
+// tap = p1*2 + p2 and cin = c.
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout,
+                                                        int Cin, int KH, int KW, int CoutPad, int standardize,
+                                                        int unshuffle) {
+    const int o = blockIdx.x;
+    const int n = Cin * KH * KW;   // elements of this filter (for unshuffle: Cin*4 with KH=KW=2)
+    const float* s = src + (size_t)o * n;
+    __shared__ double red[256];
+    double mean = 0.0, rstd = 1.0;
+    if (standardize) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+        mean = red[0] / n;
+        __syncthreads();
+        acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) { double d = s[i] - mean; acc += d * d; }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+        rstd = 1.0 / sqrt(red[0] / n + 1e-5);
+    }
+    const int taps = KH * KW;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int cin, tap;
+        if (unshuffle) { cin = i / 4; tap = i % 4; }          // i = c*4 + p1*2 + p2
+        else { cin = i / taps; tap = i % taps; }              // i = c*KH*KW + ky*KW + kx
+        dst[((size_t)tap * Cin + cin) * CoutPad + o] = (float)(((double)s[i] - mean) * rstd);
+    }
+}
+
+// packed fp32 [taps][Cin][CoutPad] -> split bf16 [taps][Cin/CK][CoutPad][CK hi | CK lo]
+__global__ __launch_bounds__(256) void split_conv_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int taps,
+                                                         int Cin, int CoutPad, int CK) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)taps * Cin * CoutPad;
+    if (i >= total) return;
+    const int n = (int)(i % CoutPad);
+    const int cin = (int)((i / CoutPad) % Cin);
+    const int tap = (int)(i / ((size_t)CoutPad * Cin));
+    const int c = cin / CK, kl = cin - c * CK;
+    const float v = w[i];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    unsigned short* row = dst + (((size_t)tap * (Cin / CK) + c) * CoutPad + n) * (2 * CK);
+    row[kl] = __builtin_bit_cast(unsigned short, hi);
+    row[CK + kl] = __builtin_bit_cast(unsigned short, lo);
+}
+
+int launch_pack_conv(const float* src, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad, int standardize,
+                     int unshuffle, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(dst, 0, (size_t)KH * KW * Cin * CoutPad * sizeof(float), st);
+    if (e != hipSuccess) { hd_set_error("pack memset failed"); return -3; }
+    hipLaunchKernelGGL(pack_conv_kernel, dim3(Cout), dim3(256), 0, st, src, dst, Cout, Cin, KH, KW, CoutPad, standardize,
+                       unshuffle);
+    return 0;
+}
+
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st) {
+    const size_t total = (size_t)taps * Cin * CoutPad;
+    hipLaunchKernelGGL(split_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, dst, taps, Cin, CoutPad, CK);
+    return 0;
+}
+
+// dst[c][dst_col0 + r] = src[r][c]  (torch Linear weight [out][in] -> [in][out_total] slab)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols, int dst_ld,
+                                 int dst_col0) {
+    __shared__ float t[32][33];
+    int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + threadIdx.x;
+        t[j][threadIdx.x] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) dst[(size_t)c * dst_ld + dst_col0 + r] = t[threadIdx.x][j];
+    }
+}
+
+int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, st, src, dst, rows, cols, dst_ld, dst_col0);
+    return 0;
+}

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -106,6 +107,8 @@ struct hd_ctx {
     Pool pool;
     float* eps_buf = nullptr; size_t eps_cap = 0;   // eps of the fused step calls
     int resB = 0, resS = 0;
+    int precision = HD_PREC_BF16X3;   // arithmetic of the wide convolutions (hd_set_precision)
+    int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
     // test-only capture of intermediates (hicdiff_hip_debug.h)
     bool capture = false;
     std::unordered_map<std::string, Act> captured;
@@ -154,6 +157,14 @@ struct Loader {
         w->KH = w->KW = KH; w->Cin = cin; w->Cout = cout; w->CoutPad = (cout + 63) / 64 * 64;
         if (!w->w) { w->w = dev((size_t)KH * KH * cin * w->CoutPad); if (!w->w) return HD_EHIP; }
         HD_TRY(launch_pack_conv((const float*)t->data, w->w, cout, cin, KH, KH, w->CoutPad, standardize ? 1 : 0, unshuffle ? 1 : 0, st));
+        w->ck = (cin % c->ck == 0) ? c->ck : 16;
+        if (!w->wsplit) {
+            void* p = nullptr;
+            if (hipMalloc(&p, (size_t)KH * KH * cin * w->CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
+            c->owned.push_back(p);
+            w->wsplit = (unsigned short*)p;
+        }
+        HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, w->ck, st));
         if (bias) HD_TRY(vec(name + ".bias", {cout}, &w->bias));
         return 0;
     }
@@ -324,6 +335,7 @@ static int probe(Run& r, const std::string& label, const Act& a) {
 
 static int run_conv(Run& r, ConvArgs& a) {
     if (r.dry) return 0;
+    a.precision = r.c->precision;
     return launch_conv(a, r.st, nullptr);
 }
 
@@ -332,7 +344,8 @@ static int run_conv(Run& r, ConvArgs& a) {
 static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* beta, int film_mode, int film_off,
                    float** A, float** Bv, float** E) {
     const int HW = a.H * a.W;
-    int slots = conv_gn_slots(a.B, a.H, a.W, C);
+    a.precision = r.c->precision;
+    int slots = conv_gn_slots(a);
     const bool fused = slots > 0;
     if (!fused) slots = (HW + 255) / 256;
     float* part = nullptr;
@@ -593,6 +606,8 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->arch = *a; c->device = device;
     c->cin0 = a->self_condition ? 2 : 1;
     c->time_in = a->dim; c->time_dim = a->dim * 4;
+    c->ck = (a->dim % 32 == 0) ? 32 : 16;
+    if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
     else { c->first_ks = 3; c->first_cout = a->dim; c->film_n = a->number_resnet * (a->sr3 ? 1 : 2) * a->dim; }
     *out = c;
@@ -698,12 +713,17 @@ int hd_randn(hd_ctx* c, float* out, int B, int S, uint64_t seed, uint64_t tile_o
 
 int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
-int hd_profile_read(hd_profile_row rows[2]) {
+int hd_set_precision(hd_ctx* c, int mode) {
+    if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3)) return HD_EINVAL;
+    c->precision = mode;
+    return HD_OK;
+}
+
+int hd_profile_read(hd_profile_row rows[HD_PROFILE_ROWS]) {
     if (!rows) return HD_EINVAL;
-    double ms[2], fl[2], by[2]; long long n[2];
+    double ms[HD_PROF_VARIANTS], fl[HD_PROF_VARIANTS], by[HD_PROF_VARIANTS]; long long n[HD_PROF_VARIANTS];
     hd_prof_collect(ms, fl, by, n);
-    static const char* names[2] = {"conv_igemm_f32_kernel<2,2,16>", "conv_igemm_f32_kernel<2,1,16>"};
-    for (int v = 0; v < 2; ++v) { rows[v].kernel = names[v]; rows[v].launches = n[v]; rows[v].total_ms = ms[v]; rows[v].flops = fl[v]; rows[v].bytes = by[v]; }
+    for (int v = 0; v < HD_PROF_VARIANTS; ++v) { rows[v].kernel = hd_prof_variant_name(v); rows[v].launches = n[v]; rows[v].total_ms = ms[v]; rows[v].flops = fl[v]; rows[v].bytes = by[v]; }
     return HD_OK;
 }
 
@@ -734,6 +754,8 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
     const bool up = mode & 1, ws = mode & 2, unsh = mode & 4, aff = mode & 8, ln = mode & 16;
     const int Cin = C0 + C1, KH = unsh ? 2 : K;
     ConvW cw; cw.KH = cw.KW = KH; cw.Cin = Cin; cw.Cout = Cout; cw.CoutPad = (Cout + 63) / 64 * 64;
+    cw.ck = (mode & 64) && Cin % 32 == 0 && C0 % 32 == 0 ? 32 : 16;
+    void* psplit = nullptr;
     void *pw = nullptr, *pst = nullptr;
     if (hipMalloc(&pw, (size_t)KH * KH * Cin * cw.CoutPad * sizeof(float)) != hipSuccess) return HD_EHIP;
     cw.w = (float*)pw; cw.bias = const_cast<float*>(bias);
@@ -745,13 +767,23 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
     else { a.H = IH; a.W = IW; a.stride = 1; a.pad = K / 2; }
     if (aff) { a.in_mode = IN_AFFINE_SILU; a.inA = A; a.inB = Bv; a.inE = E; a.in_bstride = Cin; }
     if (ln && rc == 0) {
-        if (hipMalloc(&pst, (size_t)B * IH * IW * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
-        rc = launch_ln_stats(in0, (size_t)B * IH * IW, C0, (float*)pst, st);
-        a.in_mode = IN_LAYERNORM; a.ln_stats = (float*)pst; a.ln_g = A;
+        if (mode & 128) {                      // precomputed statistics passed in Bv ([pixels][2])
+            a.ln_stats = Bv;
+        } else {
+            if (hipMalloc(&pst, (size_t)B * IH * IW * 2 * sizeof(float)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
+            rc = launch_ln_stats(in0, (size_t)B * IH * IW, C0, (float*)pst, st);
+            a.ln_stats = (float*)pst;
+        }
+        a.in_mode = IN_LAYERNORM; a.ln_g = A;
+    }
+    if ((mode & 32) && rc == 0) {
+        if (hipMalloc(&psplit, (size_t)KH * KH * Cin * cw.CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
+        rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, cw.ck, st);
+        a.cw.wsplit = (unsigned short*)psplit; a.cw.ck = cw.ck; a.precision = HD_PREC_BF16X3;
     }
     if (rc == 0) rc = launch_conv(a, st, nullptr);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(pw); if (pst) (void)hipFree(pst);
+    (void)hipFree(pw); if (pst) (void)hipFree(pst); if (psplit) (void)hipFree(psplit);
     return rc;
 }
 

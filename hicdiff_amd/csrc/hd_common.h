@@ -17,9 +17,13 @@ struct Act {
 // filled), bias [Cout].  UNet 3x3 convs are weight-standardised at pack time.
 struct ConvW {
     float* w = nullptr;
+    unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/ck][CoutPad][ck hi | ck lo] (fast path)
     float* bias = nullptr;
-    int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0;
+    int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;
 };
+
+enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
+#define HD_PROF_VARIANTS 5
 
 enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2 };
 enum EpFlags {
@@ -52,6 +56,7 @@ struct ConvArgs {
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
     // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
     float* gn_part = nullptr;
+    int precision = HD_PREC_F32;
 };
 
 #define HD_CHECK_HIP(expr)                                                                 \
@@ -66,14 +71,16 @@ struct ConvArgs {
 void hd_set_error(const std::string& msg);
 
 void hd_prof_enable(bool on);
-void hd_prof_collect(double ms[2], double flops[2], double bytes[2], long long launches[2]);
+void hd_prof_collect(double* ms, double* flops, double* bytes, long long* launches);   // HD_PROF_VARIANTS entries each
+const char* hd_prof_variant_name(int v);
 
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
-int conv_gn_slots(int B, int H, int W, int Cout);  // slots per sample the fused GN partials would use (0: not fusable)
+int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials would use (0: not fusable)
 
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
                      int standardize, int unshuffle, hipStream_t st);
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st);
 int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st);
 
 int launch_conv_small_cin(const float* x, const float* cond, const float* w, const float* bias, float* out,

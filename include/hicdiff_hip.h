@@ -113,6 +113,15 @@ int hd_load_weights(hd_ctx* ctx, const hd_named_tensor* tensors, int n, void* st
 int hd_reserve(hd_ctx* ctx, int B, int S);
 int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
 
+/* Arithmetic of the wide convolutions (every other kernel is fp32 throughout):
+ *   HD_PRECISION_F32     exact fp32 on v_mfma_f32_32x32x2_f32 (strict-parity mode, 157 TFLOP/s peak);
+ *   HD_PRECISION_BF16X3  default: operands split into two bf16 (x = hi + lo), three bf16 MFMAs per product
+ *                        with fp32 accumulation -- ~2e-5 relative error per forward, inside the 1e-3
+ *                        parity bound, at up to 5x the fp32 MFMA rate.
+ * The environment variable HICDIFF_PRECISION=f32|bf16x3 sets the default at hd_create. */
+enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1 };
+int hd_set_precision(hd_ctx* ctx, int mode);
+
 /* ---- the hot path -------------------------------------------------------------------------- */
 
 /* eps = model(x, t, x_self_cond): Unet.forward src/hicdiff.py:345-387, hicedrn_Diff.forward
@@ -172,8 +181,9 @@ typedef struct {
     double flops;
     double bytes;
 } hd_profile_row;
+#define HD_PROFILE_ROWS 5
 int hd_profile_enable(int enable);
-int hd_profile_read(hd_profile_row rows[2]);
+int hd_profile_read(hd_profile_row rows[HD_PROFILE_ROWS]);
 
 #ifdef __cplusplus
 }

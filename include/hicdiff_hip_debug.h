@@ -14,7 +14,8 @@ extern "C" {
  *   in0/in1: NHWC device tensors (in1 may be NULL), stored size IH x IW; w: torch layout
  *   [Cout][Cin][K][K] (for unshuffle: [Cout][4*Cin][1][1]); mode bits: 1 = nearest x2 upsample,
  *   2 = weight-standardise, 4 = pixel-unshuffle 2x2 stride 2, 8 = affine+SiLU input transform with
- *   A,Bv [B][Cin] (E optional), 16 = LayerNorm input transform (stats computed internally, g = A). */
+ *   A,Bv [B][Cin] (E optional), 16 = LayerNorm input transform (stats computed internally, g = A),
+ *   32 = split-bf16 x3 arithmetic instead of exact fp32, 64 = use the 32-channel K slice. */
 int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int IH, int IW, const float* w,
                   const float* bias, int Cout, int K, int mode, const float* A, const float* Bv, const float* E,
                   float* out, void* stream);

@@ -15,6 +15,14 @@ EPS_TOL = 1e-4
 CHAIN_TOL = 1e-3
 
 
+@pytest.fixture(autouse=True, params=["bf16x3", "f32"])
+def precision(request, monkeypatch):
+    """Every parity test runs twice: with the default split-bf16 x3 convolutions and with the exact
+    fp32 MFMA path (HICDIFF_PRECISION is read when the engine context is created)."""
+    monkeypatch.setenv("HICDIFF_PRECISION", request.param)
+    return request.param
+
+
 def _dev(t):
     return None if t is None else t.cuda()
 
@@ -211,6 +219,22 @@ def test_p_losses_cond_and_sr3_golden():
 
 
 # ---------------------------------------------------------------- size-independent properties at full batch size
+
+def test_precision_modes_differ_but_agree(precision):
+    """The two arithmetic paths are really different code (results differ in the last bits) and
+    agree far inside the parity bound."""
+    if precision != "bf16x3":
+        pytest.skip("compared once")
+    from hicdiff_amd import _lib as L
+    m = product_unet("uncond", 16, (1, 2))
+    x, t = tiles(5, 4, 32).cuda(), torch.tensor([1, 50, 500, 999]).cuda()
+    fast = m(x, t)
+    eng = m.engine()
+    assert eng.lib.hd_set_precision(eng.ctx, L.HD_PRECISION_F32) == 0
+    exact = m(x, t)
+    assert not torch.equal(fast, exact)
+    assert rel_err(exact, fast) < EPS_TOL
+
 
 def test_batch_independence_and_determinism_full_size():
     """Tiles are independent: eps of a 64-tile batch equals eps of its slices, bit for bit,
