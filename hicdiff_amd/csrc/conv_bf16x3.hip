@@ -146,8 +146,11 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) {
             const float* g = p.in0 + (size_t)(it_src[j] < 0 ? 0 : it_src[j]) * p.C0 + q8;
-            xr[j][0] = *reinterpret_cast<const float4*>(g);
-            xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+            xr[j][0] = xr[j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(p.ablate & 32)) {
+                xr[j][0] = *reinterpret_cast<const float4*>(g);
+                xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+            }
         }
         const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + (size_t)t.n0 * ROWB;
         HD_WLOAD(0) HD_WLOAD(1) HD_WLOAD(2) HD_WLOAD(3)
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     for (int c = 0; c < nchunks; ++c) {
         if (c > 0) __syncthreads();      // every wave is done reading the previous slice's window
         // ---- stage slice c: transform + split + LDS write of the prefetched raw values
-        {
+        if (!(p.ablate & 64)) {
             const int cc = c * CK + q8;
 #pragma unroll
             for (int j = 0; j < MAXI; ++j) {
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
                 split8(v0, v1, hi, lo);
                 if (it_src[j] < 0) { hi = make_uint4(0, 0, 0, 0); lo = hi; }   // zero padding is applied AFTER the transform
                 const int px = px0 + j * PXSTEP;
-                if (px < npx) {
+                if (px < npx && !(p.ablate & 2)) {
                     char* d = Xs + px * PITCH + q8 * 2;
                     *reinterpret_cast<uint4*>(d) = hi;
                     *reinterpret_cast<uint4*>(d + 2 * CK) = lo;
@@ -181,8 +184,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 #pragma unroll
             for (int j = 0; j < MAXI; ++j) {
                 const float* g = src + (size_t)(it_src[j] < 0 ? 0 : it_src[j]) * Csrc + coff + q8;
-                xr[j][0] = *reinterpret_cast<const float4*>(g);
-                xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+                if (!(p.ablate & 32)) {
+                    xr[j][0] = *reinterpret_cast<const float4*>(g);
+                    xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+                }
             }
         }
         int ky = 0, kx = 0;
@@ -190,10 +195,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
             // weight slab (c, tap) -> LDS; prefetch the next slab into registers
             {
                 char* dst = Ws + buf * BN * PITCH;
-                HD_WSTORE(0) HD_WSTORE(1) HD_WSTORE(2) HD_WSTORE(3)
+                if (!(p.ablate & 4)) { HD_WSTORE(0) HD_WSTORE(1) HD_WSTORE(2) HD_WSTORE(3) }
                 int tapn = tap + 1, cn = c;
                 if (tapn == ntaps) { tapn = 0; cn = c + 1; }
-                if (cn < nchunks) {
+                if (cn < nchunks && !(p.ablate & 256)) {
                     const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + ((size_t)(tapn * nchunks + cn) * p.CoutPad + t.n0) * ROWB;
                     HD_WLOAD(0) HD_WLOAD(1) HD_WLOAD(2) HD_WLOAD(3)
                 }
@@ -201,6 +206,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
             __syncthreads();             // X window (if just staged) and weight slab visible
             const char* Wb = Ws + buf * BN * PITCH;
             const int tapoff = (ky * p.LW + kx) * PITCH;
+            if (!(p.ablate & 8))
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     (void)nit; (void)w1; (void)w2; (void)w3;
 #undef HD_WLOAD
 #undef HD_WSTORE
-    conv_epilogue<TM, TN, WM>(p, t, acc, rowpix, rowb);
+    conv_epilogue<BM, BN, TM, TN>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
 }
 
 template <typename K>

@@ -18,6 +18,7 @@ struct ConvKArgs {
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     float* out; float* gn_part; int gn_slots;
+    int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };
 
 // x * sigmoid(x) with the hardware exp2 / reciprocal (relative error ~1e-7)
@@ -112,46 +113,107 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
     return v;
 }
 
-template <int TM, int TN, int WM>
+// Epilogue: the accumulator tile goes through LDS once so that every global access of the epilogue is a
+// 16-byte row-contiguous access (a 32x32 MFMA C tile holds one column per lane: stored directly that is
+// 64 four-byte stores per lane plus per-element address arithmetic, which measured ~35 % of the kernel).
+//   stage: LDS, BM x (BN + 4) floats, overlays the operand buffers (all MFMA reads are done).
+//   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
+//   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
+template <int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
-                                              const int* rowb) {
+                                              const int* rowb, float* stage) {
+    constexpr int EP = BN + 4, CQ = BN / 4, RPP = 256 / CQ, NPASS = BM / RPP;
+    __syncthreads();                       // every wave has finished reading the last tap's operands
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int n = t.n0 + t.wn * 32 * TN + tn * 32 + t.l31;
-        const bool nok = n < p.Cout;
-        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+    for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = t.wn * 32 * TN + tn * 32 + t.l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = t.wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;
-                const int pix = rowpix[m];
-                if (pix < 0 || !nok) continue;
-                float v = acc[tm][tn][r] + bias;
-                s1 += v; s2 += v * v;
-                if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
-                    const int o = rowb[m] * p.ep_bstride + n;
-                    if (p.ep & EP_FILM_SILU) v = v * (p.epScale[o] + 1.f) + p.epShift[o];
-                    else v = v + p.epShift[o];
-                    v = silu_f(v);
-                }
-                if (p.ep & EP_RES) v = p.alpha * v + p.res[(size_t)pix * p.Cout + n];
-                if (p.ep & EP_RES_AFFINE_SILU) {
-                    const int o = rowb[m] * p.res_bstride + n;
-                    v += silu_f(p.res[(size_t)pix * p.Cout + n] * p.resA[o] + p.resB[o]);
-                }
-                p.out[(size_t)pix * p.Cout + n] = v;
+                stage[m * EP + col] = acc[tm][tn][r];
             }
         }
-        if (p.gn_part) {  // TB == 1: every row of this workgroup belongs to sample b0
-            s1 += __shfl_xor(s1, 32);
-            s2 += __shfl_xor(s2, 32);
-            if (t.half == 0 && nok) {
-                const int slot = (t.tile_y * p.tiles_x + t.tile_x) * WM + t.wm;
-                float* d = p.gn_part + (((size_t)t.b0 * p.gn_slots + slot) * p.Cout + n) * 2;
-                d[0] = s1; d[1] = s2;
+    __syncthreads();
+    const int cq = t.tid % CQ, rg = t.tid / CQ;
+    const int n = t.n0 + cq * 4;
+    const int nvalid = p.Cout - n;         // >= 4: all four channels of this thread exist
+    const bool vec = nvalid >= 4 && (p.Cout & 3) == 0;
+    float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nvalid) bias[j] = p.bias[n + j];
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nvalid > 0 && !(p.ablate & 128)) {
+#pragma unroll 4
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int m = pass * RPP + rg;
+            const int pix = rowpix[m];
+            if (pix < 0) continue;
+            const float4 a4 = *reinterpret_cast<const float4*>(stage + m * EP + cq * 4);
+            float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+            const size_t o = (size_t)pix * p.Cout + n;
+            if (vec) {
+                if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                    const int fo = rowb[m] * p.ep_bstride + n;
+                    const float4 sh = *reinterpret_cast<const float4*>(p.epShift + fo);
+                    if (p.ep & EP_FILM_SILU) {
+                        const float4 sc = *reinterpret_cast<const float4*>(p.epScale + fo);
+                        v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
+                        v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;
+                    } else { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
+                }
+                if (p.ep & EP_RES) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                    v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w;
+                }
+                if (p.ep & EP_RES_AFFINE_SILU) {
+                    const int fo = rowb[m] * p.res_bstride + n;
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                    const float4 ra = *reinterpret_cast<const float4*>(p.resA + fo);
+                    const float4 rb = *reinterpret_cast<const float4*>(p.resB + fo);
+                    v[0] += silu_f(rr.x * ra.x + rb.x); v[1] += silu_f(rr.y * ra.y + rb.y);
+                    v[2] += silu_f(rr.z * ra.z + rb.z); v[3] += silu_f(rr.w * ra.w + rb.w);
+                }
+                if (!(p.ablate & 1) || v[0] == 123456.789f) *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (j >= nvalid) break;
+                    float x = v[j];
+                    if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                        const int fo = rowb[m] * p.ep_bstride + n + j;
+                        x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
+                        x = silu_f(x);
+                    }
+                    if (p.ep & EP_RES) x = p.alpha * x + p.res[o + j];
+                    if (p.ep & EP_RES_AFFINE_SILU) {
+                        const int fo = rowb[m] * p.res_bstride + n + j;
+                        x += silu_f(p.res[o + j] * p.resA[fo] + p.resB[fo]);
+                    }
+                    p.out[o + j] = x;
+                }
             }
+        }
+    }
+    if (p.gn_part) {   // TB == 1: every row of this workgroup belongs to sample b0
+        __syncthreads();                   // stage is free again: reuse it as [RPP][BN][2]
+        float* red = stage;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[(rg * BN + cq * 4 + j) * 2] = s1[j]; red[(rg * BN + cq * 4 + j) * 2 + 1] = s2[j]; }
+        __syncthreads();
+        if (t.tid < BN && t.n0 + t.tid < p.Cout) {
+            float a = 0.f, b = 0.f;
+            for (int g = 0; g < RPP; ++g) { a += red[(g * BN + t.tid) * 2]; b += red[(g * BN + t.tid) * 2 + 1]; }
+            const int slot = t.tile_y * p.tiles_x + t.tile_x;
+            float* d = p.gn_part + (((size_t)t.b0 * p.gn_slots + slot) * p.Cout + t.n0 + t.tid) * 2;
+            d[0] = a; d[1] = b;
         }
     }
 }

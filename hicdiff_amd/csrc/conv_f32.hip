@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvKArgs p) {
         if (++kx == p.KW) { kx = 0; ++ky; }
         if (tap == 0) { ky = 0; kx = 0; }
     }
-    conv_epilogue<TM, TN, WM>(p, t, acc, rowpix, rowb);
+    conv_epilogue<BM, BN, TM, TN>(p, t, acc, rowpix, rowb, Ws);
 }
 
 template <typename K>

@@ -19,6 +19,8 @@
 //     of the epilogue with one cross-half exchange.
 #include "conv_device.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <tuple>
 #include <vector>
@@ -122,14 +124,15 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
     const int LH = (pl.g.TH - 1) * a.stride + a.cw.KH, LW = (pl.g.TW - 1) * a.stride + a.cw.KW;
     const int npx = pl.g.TB * LH * LW, npx4 = (npx + 3) & ~3;
-    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + wbytes + (size_t)npx * pl.pitch;
+    const size_t stage = (size_t)pl.BM * (pl.BN + 4) * 4;      // epilogue staging overlays the operand buffers
+    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(wbytes + (size_t)npx * pl.pitch, stage);
     return pl;
 }
 
 int conv_gn_slots(const ConvArgs& a) {
     const ConvPlan pl = plan_conv(a);
     if (pl.g.TB != 1) return 0;
-    return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW) * pl.WM;
+    return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW);
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
@@ -144,6 +147,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
     k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
     k.out = a.out;
+    static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
+    k.ablate = ablate;
     const ConvPlan pl = plan_conv(a);
     if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
         hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");
@@ -156,7 +161,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.tiles_y = (a.H + g.TH - 1) / g.TH; k.tiles_x = (a.W + g.TW - 1) / g.TW;
     k.ntiles_n = k.CoutPad / pl.BN;
     k.gn_part = nullptr; k.gn_slots = 0;
-    if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x * pl.WM; }
+    if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
     L.lds = pl.lds; L.variant = pl.variant; L.ck = pl.ck; L.cfg = pl.cfg;
     if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }

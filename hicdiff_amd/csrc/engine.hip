@@ -411,11 +411,12 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
     Act att; HD_TRY(r.act(H, W, 128, &att));
     if (w.linear) {
         float* ctx; HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
+        float* scr; HD_TRY(r.alloc(linattn_scratch_floats(r.B, HW, heads), &scr));
         if (!r.dry) {
-            HD_TRY(launch_linattn_context(qkv.p, r.B, HW, heads, ctx, r.st));
+            HD_TRY(launch_linattn_context(qkv.p, r.B, HW, heads, scr, ctx, r.st));
             HD_TRY(launch_linattn_apply(qkv.p, ctx, r.B, HW, heads, att.p, r.st));
         }
-        r.free(ctx);
+        r.free(ctx); r.free(scr);
     } else if (!r.dry) {
         HD_TRY(launch_attn_full(qkv.p, r.B, HW, heads, att.p, r.st));
     }

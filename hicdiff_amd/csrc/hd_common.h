@@ -99,7 +99,8 @@ int launch_affine_silu_add(const float* h, const float* A, const float* Bv, cons
                            int B, int HW, int C, hipStream_t st);
 int launch_ln_stats(const float* x, size_t P, int C, float* stats, hipStream_t st);
 int launch_ln_residual(const float* y, const float* g, const float* res, float* out, size_t P, int C, hipStream_t st);
-int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* ctx, hipStream_t st);
+size_t linattn_scratch_floats(int B, int HW, int heads);
+int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* scratch, float* ctx, hipStream_t st);
 int launch_linattn_apply(const float* qkv, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
 

@@ -210,40 +210,47 @@ int launch_gn_partial(const float* x, int B, int HW, int C, float* part, int* sl
 // film_mode 0: none; 1: x*(scale+1)+shift with [scale | shift] at film[b*bs + off + {0..C, C..2C}]
 // (src/hicdiff.py:166-168,191); 2: SR3 additive embedding AFTER the SiLU (src/hicdiff_sr3.py:249),
 // exported as E.
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int slots, int B, int HW, int C,
-                                                          int groups, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, const float* __restrict__ film,
-                                                          int film_bstride, int film_off, int film_mode,
-                                                          float* __restrict__ A, float* __restrict__ Bv, float* __restrict__ E) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * C) return;
-    const int b = i / C, c = i % C, cg = C / groups, g = c / cg;
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, int slots, int B, int HW, int C,
+                                                         int groups, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ film,
+                                                         int film_bstride, int film_off, int film_mode,
+                                                         float* __restrict__ A, float* __restrict__ Bv, float* __restrict__ E) {
+    // one wave per (sample, group): lanes stride over the group's slots x channels partial sums (fixed
+    // order, so the result does not depend on anything but the tiling), fp64 combine.
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups, lane = threadIdx.x;
+    const int cg = C / groups, total = slots * cg;
     double s1 = 0.0, s2 = 0.0;
-    for (int s = 0; s < slots; ++s) {
-        const float* d = part + (((size_t)b * slots + s) * C + g * cg) * 2;
-        for (int j = 0; j < cg; ++j) { s1 += d[2 * j]; s2 += d[2 * j + 1]; }
+    for (int i = lane; i < total; i += 64) {
+        const int s = i / cg, j = i - s * cg;
+        const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)b * slots + s) * C + g * cg + j) * 2);
+        s1 += v.x; s2 += v.y;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     const double n = (double)HW * cg;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-    float a = rstd * gamma[c];
-    float bb = beta[c] - (float)mean * a;
-    if (film_mode == 1) {
-        const float sc = film[(size_t)b * film_bstride + film_off + c] + 1.f;
-        const float sf = film[(size_t)b * film_bstride + film_off + C + c];
-        a *= sc; bb = bb * sc + sf;
-    } else if (film_mode == 2) {
-        E[i] = film[(size_t)b * film_bstride + film_off + c];
+    for (int j = lane; j < cg; j += 64) {
+        const int c = g * cg + j, i = b * C + c;
+        float a = rstd * gamma[c];
+        float bb = beta[c] - (float)mean * a;
+        if (film_mode == 1) {
+            const float sc = film[(size_t)b * film_bstride + film_off + c] + 1.f;
+            const float sf = film[(size_t)b * film_bstride + film_off + C + c];
+            a *= sc; bb = bb * sc + sf;
+        } else if (film_mode == 2) {
+            E[i] = film[(size_t)b * film_bstride + film_off + c];
+        }
+        A[i] = a; Bv[i] = bb;
     }
-    A[i] = a; Bv[i] = bb;
 }
 
 int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma, const float* beta,
                        const float* film, int film_bstride, int film_off, int film_mode, float* A, float* Bv, float* E,
                        hipStream_t st) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, st, part, slots, B, HW, C, groups, gamma,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, slots, B, HW, C, groups, gamma,
                        beta, film, film_bstride, film_off, film_mode, A, Bv, E);
     return check_launch("gn_finalize");
 }
@@ -348,32 +355,37 @@ int launch_ln_residual(const float* y, const float* g, const float* res, float* 
 // ------------------------------------------------------------------------------------------------
 // LinearAttention (src/hicdiff.py:212-227), heads x 32.  qkv is [B][HW][3*heads*32] with q | k | v
 // blocks of heads*32 channels.
-//   context[d][e] = sum_n softmax_n(k[d][:])[n] * v[e][n] / HW        (one workgroup per (b, head))
-__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, int HW, int heads,
-                                                              float* __restrict__ ctx) {
+//   context[d][e] = sum_n softmax_n(k[d][:])[n] * v[e][n] / HW
+// Tokens are cut into SPLIT-token ranges: one workgroup per (b, head, range) produces the range's column
+// maxima, exp-sums and un-normalised 32x32 context relative to its own maxima; linattn_combine rescales
+// the ranges to the global maxima and normalises (flash-style two-level softmax, fixed order).
+#define LINATTN_SPLIT 512
+__global__ __launch_bounds__(256) void linattn_context_kernel(const float* __restrict__ qkv, int HW, int heads, int nsplit,
+                                                              float* __restrict__ pmax, float* __restrict__ psum,
+                                                              float* __restrict__ pctx) {
     constexpr int D = 32, CH = 64;
     __shared__ float ks[CH][D + 1];
     __shared__ float vs[CH][D];
     __shared__ float red[8][D];
-    __shared__ float kmax[D], ksum[D];
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    __shared__ float kmax[D];
+    const int bh = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int b = bh / heads, h = bh % heads, tid = threadIdx.x;
     const int C3 = 3 * heads * D;
     const float* base = qkv + (size_t)b * HW * C3;
     const int koff = heads * D + h * D, voff = 2 * heads * D + h * D;
+    const int nb = sp * LINATTN_SPLIT, ne = min(HW, nb + LINATTN_SPLIT);
     const int d = tid & 31, sub = tid >> 5;   // 8 sub-rows x 32 d
-    // pass 1: max over n of k[n][d]
     float mx = -3.0e38f;
-    for (int n = sub; n < HW; n += 8) mx = fmaxf(mx, base[(size_t)n * C3 + koff + d]);
+    for (int n = nb + sub; n < ne; n += 8) mx = fmaxf(mx, base[(size_t)n * C3 + koff + d]);
     red[sub][d] = mx;
     __syncthreads();
     if (tid < D) { float m = red[0][tid]; for (int j = 1; j < 8; ++j) m = fmaxf(m, red[j][tid]); kmax[tid] = m; }
     __syncthreads();
-    // pass 2: p = exp(k - max); sum_d; ctx[d][e] += p[n][d] * v[n][e].  thread -> (d = tid/8, e4 = tid%8)
-    const int dd = tid >> 3, e0 = (tid & 7) * 4;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, psum = 0.f;
+    const int dd = tid >> 3, e0 = (tid & 7) * 4;   // thread -> (d = tid/8, four e)
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f, ps = 0.f;
     const float m_d = kmax[dd];
-    for (int n0 = 0; n0 < HW; n0 += CH) {
-        const int cnt = min(CH, HW - n0);
+    for (int n0 = nb; n0 < ne; n0 += CH) {
+        const int cnt = min(CH, ne - n0);
         __syncthreads();
         for (int i = tid; i < CH * D; i += 256) {
             int r = i / D, c = i % D;
@@ -385,18 +397,45 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
         for (int r = 0; r < cnt; ++r) {
             const float pexp = __expf(ks[r][dd] - m_d);
             const float4 vv = *reinterpret_cast<const float4*>(&vs[r][e0]);
-            psum += pexp;
+            ps += pexp;
             acc0 += pexp * vv.x; acc1 += pexp * vv.y; acc2 += pexp * vv.z; acc3 += pexp * vv.w;
         }
     }
-    const float inv = 1.f / (psum * (float)HW);
-    float* o = ctx + ((size_t)blockIdx.x * D + dd) * D + e0;
-    o[0] = acc0 * inv; o[1] = acc1 * inv; o[2] = acc2 * inv; o[3] = acc3 * inv;
-    (void)ksum;
+    const size_t slot = (size_t)bh * nsplit + sp;
+    if ((tid & 7) == 0) { pmax[slot * D + dd] = m_d; psum[slot * D + dd] = ps; }
+    *reinterpret_cast<float4*>(pctx + (slot * D + dd) * D + e0) = make_float4(acc0, acc1, acc2, acc3);
 }
 
-int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(linattn_context_kernel, dim3(B * heads), dim3(256), 0, st, qkv, HW, heads, ctx);
+__global__ __launch_bounds__(256) void linattn_combine_kernel(const float* __restrict__ pmax, const float* __restrict__ psum,
+                                                              const float* __restrict__ pctx, int nsplit, int HW,
+                                                              float* __restrict__ ctx) {
+    constexpr int D = 32;
+    const int bh = blockIdx.x, tid = threadIdx.x, dd = tid >> 3, e0 = (tid & 7) * 4;
+    float gm = -3.0e38f;
+    for (int s = 0; s < nsplit; ++s) gm = fmaxf(gm, pmax[((size_t)bh * nsplit + s) * D + dd]);
+    float sum = 0.f, a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const size_t slot = (size_t)bh * nsplit + s;
+        const float f = __expf(pmax[slot * D + dd] - gm);
+        sum += psum[slot * D + dd] * f;
+        const float4 c = *reinterpret_cast<const float4*>(pctx + (slot * D + dd) * D + e0);
+        a0 += c.x * f; a1 += c.y * f; a2 += c.z * f; a3 += c.w * f;
+    }
+    const float inv = 1.f / (sum * (float)HW);
+    *reinterpret_cast<float4*>(ctx + ((size_t)bh * D + dd) * D + e0) = make_float4(a0 * inv, a1 * inv, a2 * inv, a3 * inv);
+}
+
+size_t linattn_scratch_floats(int B, int HW, int heads) {
+    const int nsplit = (HW + LINATTN_SPLIT - 1) / LINATTN_SPLIT;
+    return (size_t)B * heads * nsplit * (32 + 32 + 32 * 32);
+}
+
+int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* scratch, float* ctx, hipStream_t st) {
+    const int nsplit = (HW + LINATTN_SPLIT - 1) / LINATTN_SPLIT;
+    const size_t slots = (size_t)B * heads * nsplit;
+    float* pmax = scratch; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
+    hipLaunchKernelGGL(linattn_context_kernel, dim3((unsigned)slots), dim3(256), 0, st, qkv, HW, heads, nsplit, pmax, psum, pctx);
+    hipLaunchKernelGGL(linattn_combine_kernel, dim3(B * heads), dim3(256), 0, st, pmax, psum, pctx, nsplit, HW, ctx);
     return check_launch("linattn_context");
 }
 
