@@ -145,13 +145,21 @@ def main():
         diff._step_inplace(img, t, cond)
         t -= 1
     barrier()
-    lib.hd_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         diff._step_inplace(img, t, cond)
         t -= 1
     barrier()
     elapsed = time.perf_counter() - t0
+    # Roofline of the dominant kernel: the same step, launched eagerly with a HIP event pair around every
+    # convolution launch on its stream (the timed region above replays a captured hipGraph of the step,
+    # inside which per-launch events cannot be recorded).
+    prof_steps = max(1, min(args.steps, 5))
+    lib.hd_profile_enable(1)
+    for _ in range(prof_steps):
+        diff._step_inplace(img, t, cond)
+        t -= 1
+    barrier()
     rows = (L.HdProfileRow * L.HD_PROFILE_ROWS)()
     lib.hd_profile_read(rows)
     lib.hd_profile_enable(0)
@@ -185,7 +193,8 @@ def main():
                           if split else "exact-fp32 MFMA peak"),
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),
             "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
-            "conv_time_share": round(sum(r.total_ms for r in rows) * 1e-3 / elapsed, 4),
+            "conv_time_share": round(sum(r.total_ms for r in rows) * 1e-3 / (prof_steps * sec_per_step), 4),
+            "profiled_steps": prof_steps,
             "whole_step": {
                 "flop_frac_of_f32_mfma_peak": round(w["flop"] * B / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "hbm_frac_algorithmic": round((w["act_bytes"] * B + w["w_bytes"]) / sec_per_step / 1e9 / PEAK_HBM_GBS, 4),

@@ -69,6 +69,7 @@ SYMBOLS = {
     "hd_profile_enable": (C.c_int, [C.c_int]),
     "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow)]),
     "hd_set_precision": (C.c_int, [_P, C.c_int]),
+    "hd_set_graphs": (C.c_int, [_P, C.c_int]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
 }
 

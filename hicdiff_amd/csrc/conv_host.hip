@@ -30,6 +30,7 @@ struct ProfRec { int variant; double flops, bytes; hipEvent_t e0, e1; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static ProfRec g_cur;
+bool hd_prof_is_on() { return g_prof_on; }
 void hd_prof_enable(bool on) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();

@@ -109,6 +109,14 @@ struct hd_ctx {
     int resB = 0, resS = 0;
     int precision = HD_PREC_BF16X3;   // arithmetic of the wide convolutions (hd_set_precision)
     int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
+    // hipGraph replay of the fused sampler steps (device-generated noise only): one graph per
+    // (kind, B, S, tensor addresses); the step's scalars are written to `sp_dev` by a 1-thread kernel.
+    struct StepGraph { int kind, B, S; const void *x, *aux, *x0; int seen; hipGraphExec_t exec; };
+    std::vector<StepGraph> graphs;
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    StepParams* sp_dev = nullptr;
+    bool use_graphs = true;
     // test-only capture of intermediates (hicdiff_hip_debug.h)
     bool capture = false;
     std::unordered_map<std::string, Act> captured;
@@ -438,7 +446,7 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
     return 0;
 }
 
-static int time_and_film(Run& r, const void* t, int t_kind, float tval, bool uniform, float** film_out) {
+static int time_and_film(Run& r, const void* t, int t_kind, float tval, bool uniform, const StepParams* sp, float** film_out) {
     hd_ctx* c = r.c;
     r.Bt = uniform ? 1 : r.B;
     float *temb, *tact, *film;
@@ -446,7 +454,7 @@ static int time_and_film(Run& r, const void* t, int t_kind, float tval, bool uni
     HD_TRY(r.alloc((size_t)r.Bt * c->time_dim, &tact));
     HD_TRY(r.alloc((size_t)r.Bt * c->film_n, &film));
     if (!r.dry) {
-        HD_TRY(launch_time_mlp(uniform ? nullptr : t, t_kind, tval, c->arch.sr3, r.Bt, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t,
+        HD_TRY(launch_time_mlp(uniform ? nullptr : t, t_kind, tval, sp, c->arch.sr3, r.Bt, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t,
                                c->b3, temb, tact, r.st));
         HD_TRY(launch_film(tact, r.Bt, c->time_dim, c->film_wt, c->film_b, c->film_n, film, r.st));
     }
@@ -565,7 +573,7 @@ static int hicedrn_forward(Run& r, const float* x, const float* cond, float* eps
 }
 
 static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float tval, bool uniform, const float* cond, float* eps,
-                   int B, int S, hipStream_t st, bool dry) {
+                   int B, int S, hipStream_t st, bool dry, const StepParams* sp = nullptr) {
     if (B < 1 || S < 8) return fail(c, HD_EINVAL, "bad batch or tile size");
     if (c->arch.kind == HD_ARCH_UNET) {
         int div = 1; for (int i = 0; i + 1 < c->arch.n_mults; ++i) div *= 2;
@@ -577,7 +585,7 @@ static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float t
     Run r{c, st, dry, B, S, B, nullptr, 0};
     c->pool.reset(dry);
     float* film = nullptr;
-    HD_TRY(time_and_film(r, t, t_kind, tval, uniform, &film));
+    HD_TRY(time_and_film(r, t, t_kind, tval, uniform, sp, &film));
     int rc = c->arch.kind == HD_ARCH_UNET ? unet_forward(r, x, cond, eps) : hicedrn_forward(r, x, cond, eps);
     r.free(film);
     return rc;
@@ -608,6 +616,7 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->cin0 = a->self_condition ? 2 : 1;
     c->time_in = a->dim; c->time_dim = a->dim * 4;
     c->ck = (a->dim % 32 == 0) ? 32 : 16;
+    if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0;
     if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
     else { c->first_ks = 3; c->first_cout = a->dim; c->film_n = a->number_resnet * (a->sr3 ? 1 : 2) * a->dim; }
@@ -621,6 +630,11 @@ void hd_destroy(hd_ctx* c) {
     for (void* p : c->owned) hipFree(p);
     if (c->pool.base) hipFree(c->pool.base);
     if (c->eps_buf) hipFree(c->eps_buf);
+    for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (c->sp_dev) (void)hipFree(c->sp_dev);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->gstream) (void)hipStreamDestroy(c->gstream);
     delete c;
 }
 
@@ -652,6 +666,8 @@ int hd_reserve(hd_ctx* c, int B, int S) {
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
     if (need > c->pool.cap) {
         if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        c->graphs.clear();                       // captured addresses die with the old block
         if (c->pool.base) hipFree(c->pool.base);
         c->pool.base = nullptr; c->pool.cap = 0;
         void* p = nullptr;
@@ -661,6 +677,8 @@ int hd_reserve(hd_ctx* c, int B, int S) {
     const size_t en = (size_t)B * S * S;
     if (en > c->eps_cap) {
         if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
         if (c->eps_buf) hipFree(c->eps_buf);
         void* p = nullptr;
         if (hipMalloc(&p, en * sizeof(float)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(eps) failed");
@@ -675,25 +693,88 @@ int hd_eps_forward(hd_ctx* c, const float* x, const void* t, int t_kind, const f
     return keep_err(c, forward(c, x, t, t_kind, 0.f, false, cond, eps, B, S, (hipStream_t)stream, false));
 }
 
+// One fused sampler step: eps-net + update.  kind 0: ancestral (aux = cond), 1: DDRM (aux = y).
+static int step_body(hd_ctx* c, int kind, float* x, const float* aux, const float* noise, const StepParams& v, float* x0_out,
+                     int B, int S, hipStream_t st, const StepParams* sp) {
+    const float* cond = kind == 0 ? aux : nullptr;
+    HD_TRY(forward(c, x, nullptr, HD_T_FLOAT32, v.f[0], true, cond, c->eps_buf, B, S, st, false, sp));
+    if (kind == 0)
+        return launch_ddpm_update(x, c->eps_buf, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], x0_out, B, S, v.seed, v.tile_off, v.step, sp, st);
+    return launch_ddrm_update(x, c->eps_buf, aux, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], v.f[6], v.f[7], v.f[8], x0_out, B, S, v.seed,
+                              v.tile_off, v.step, sp, st);
+}
+
+static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float* noise, const StepParams& v, float* x0_out, int B,
+                    int S, hipStream_t user) {
+    if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
+    // Replayed noise changes address every step and event profiling records per launch: both run eagerly.
+    if (!c->use_graphs || noise != nullptr || hd_prof_is_on() || c->capture) return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
+    if (!c->gstream) {
+        if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&c->sp_dev, sizeof(StepParams)) != hipSuccess)
+            return fail(c, HD_EHIP, "graph stream setup failed");
+    }
+    hd_ctx::StepGraph* g = nullptr;
+    for (auto& e : c->graphs) if (e.kind == kind && e.B == B && e.S == S && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
+    if (!g) {
+        if (c->graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
+            if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec);
+            c->graphs.erase(c->graphs.begin());
+        }
+        c->graphs.push_back({kind, B, S, x, aux, x0_out, 0, nullptr});
+        g = &c->graphs.back();
+    }
+    // order after the caller's stream, run on the engine's capturable stream, hand back
+    if (hipEventRecord(c->ev_in, user) != hipSuccess || hipStreamWaitEvent(c->gstream, c->ev_in, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+    HD_TRY(launch_set_step_params(c->sp_dev, v, c->gstream));
+    int rc = 0;
+    if (g->seen < 1) {                    // first call: eager (sets function attributes, warms caches)
+        rc = step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, c->gstream, c->sp_dev);
+        g->seen++;
+    } else {
+        if (!g->exec) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail(c, HD_EHIP, "hipStreamBeginCapture failed");
+            rc = step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, c->gstream, c->sp_dev);
+            hipError_t e1 = hipStreamEndCapture(c->gstream, &graph);
+            if (rc != 0 || e1 != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc ? rc : fail(c, HD_EHIP, "hipStreamEndCapture failed"); }
+            hipError_t e2 = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e2 != hipSuccess) { g->exec = nullptr; return fail(c, HD_EHIP, "hipGraphInstantiate failed"); }
+        }
+        if (hipGraphLaunch(g->exec, c->gstream) != hipSuccess) return fail(c, HD_EHIP, "hipGraphLaunch failed");
+    }
+    if (hipEventRecord(c->ev_out, c->gstream) != hipSuccess || hipStreamWaitEvent(user, c->ev_out, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+    return rc;
+}
+
 int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, const hd_ddpm_coef* k, float* x0_out, int B, int S,
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
     if (!c || !x || !k) return HD_EINVAL;
-    if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
-    hipStream_t st = (hipStream_t)stream;
-    HD_TRY(keep_err(c, forward(c, x, nullptr, HD_T_FLOAT32, k->time_value, true, cond, c->eps_buf, B, S, st, false)));
-    return keep_err(c, launch_ddpm_update(x, c->eps_buf, noise, k->sqrt_recip_alphas_cumprod, k->sqrt_recipm1_alphas_cumprod,
-                                          k->posterior_mean_coef1, k->posterior_mean_coef2, k->sigma, x0_out, B, S, seed, tile_offset,
-                                          step, st));
+    if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
+    if ((c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
+    StepParams v{};
+    v.f[0] = k->time_value; v.f[1] = k->sqrt_recip_alphas_cumprod; v.f[2] = k->sqrt_recipm1_alphas_cumprod;
+    v.f[3] = k->posterior_mean_coef1; v.f[4] = k->posterior_mean_coef2; v.f[5] = k->sigma;
+    v.step = step; v.seed = seed; v.tile_off = tile_offset;
+    return keep_err(c, run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream));
 }
 
 int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_ddrm_coef* k, float* x0_out, int B, int S,
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
     if (!c || !x || !y || !k) return HD_EINVAL;
-    if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
-    hipStream_t st = (hipStream_t)stream;
-    HD_TRY(keep_err(c, forward(c, x, nullptr, HD_T_FLOAT32, k->time_value, true, nullptr, c->eps_buf, B, S, st, false)));
-    return keep_err(c, launch_ddrm_update(x, c->eps_buf, y, z, k->sqrt_at, k->sqrt_1m_at, k->sqrt_at_next, k->sigma_next, k->sigma_0,
-                                          k->etaA, k->etaB, k->etaC, x0_out, B, S, seed, tile_offset, step, st));
+    if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
+    StepParams v{};
+    v.f[0] = k->time_value; v.f[1] = k->sqrt_at; v.f[2] = k->sqrt_1m_at; v.f[3] = k->sqrt_at_next; v.f[4] = k->sigma_next;
+    v.f[5] = k->sigma_0; v.f[6] = k->etaA; v.f[7] = k->etaB; v.f[8] = k->etaC;
+    v.step = step; v.seed = seed; v.tile_off = tile_offset;
+    return keep_err(c, run_step(c, 1, x, y, z, v, x0_out, B, S, (hipStream_t)stream));
+}
+
+int hd_set_graphs(hd_ctx* c, int enable) {
+    if (!c) return HD_EINVAL;
+    c->use_graphs = enable != 0;
+    return HD_OK;
 }
 
 int hd_q_sample(hd_ctx* c, const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S, void* stream) {

@@ -23,6 +23,11 @@ struct ConvW {
 };
 
 enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
+
+// Per-step scalars of a fused sampler step, resident in device memory when the step is replayed from a
+// hipGraph: f[0] = time value; ddpm: f[1..5] = recip, recipm1, coef1, coef2, sigma; ddrm: f[1..8] =
+// sqrt_at, sqrt_1m_at, sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC.
+struct StepParams { float f[12]; uint32_t step; uint32_t pad; uint64_t seed; uint64_t tile_off; };
 #define HD_PROF_VARIANTS 5
 
 enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2 };
@@ -71,6 +76,7 @@ struct ConvArgs {
 void hd_set_error(const std::string& msg);
 
 void hd_prof_enable(bool on);
+bool hd_prof_is_on();
 void hd_prof_collect(double* ms, double* flops, double* bytes, long long* launches);   // HD_PROF_VARIANTS entries each
 const char* hd_prof_variant_name(int v);
 
@@ -87,7 +93,7 @@ int launch_conv_small_cin(const float* x, const float* cond, const float* w, con
                           int B, int S, int KS, int Cin, int Cout, hipStream_t st);
 int launch_rowdot(const float* x, const float* w, const float* bias, float* out, size_t P, int C, hipStream_t st);
 
-int launch_time_mlp(const void* t, int t_kind, float tval, int sr3, int Bt, int dim, int time_dim, const float* w1t,
+int launch_time_mlp(const void* t, int t_kind, float tval, const StepParams* sp, int sr3, int Bt, int dim, int time_dim, const float* w1t,
                     const float* b1, const float* w3t, const float* b3, float* temb, float* temb_act, hipStream_t st);
 int launch_film(const float* act, int Bt, int K, const float* wt, const float* bias, int N, float* out, hipStream_t st);
 
@@ -106,10 +112,12 @@ int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hip
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,
                        float coef2, float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off,
-                       uint32_t step, hipStream_t st);
+                       uint32_t step, const StepParams* sp, hipStream_t st);
 int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
                        float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC,
-                       float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st);
+                       float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
+                       hipStream_t st);
+int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st);
 int launch_q_sample(const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S,
                     hipStream_t st);
 int launch_loss(const float* pred, const float* target, int l2, float* out, int B, int S, hipStream_t st);

@@ -107,7 +107,7 @@ int launch_rowdot(const float* x, const float* w, const float* bias, float* out,
 // (src/hicdiff_sr3.py:155-165), then Linear -> exact GELU -> Linear (src/hicdiff.py:300-305).
 // One workgroup per embedding row (Bt = 1 when every tile shares the timestep).  w1t/w3t are the
 // Linear weights transposed to [in][out] so lanes read consecutive outputs.
-__global__ __launch_bounds__(256) void time_mlp_kernel(const void* __restrict__ t, int t_kind, float tval, int sr3, int dim, int time_dim,
+__global__ __launch_bounds__(256) void time_mlp_kernel(const void* __restrict__ t, int t_kind, float tval, const StepParams* __restrict__ sp, int sr3, int dim, int time_dim,
                                                        const float* __restrict__ w1t, const float* __restrict__ b1,
                                                        const float* __restrict__ w3t, const float* __restrict__ b3,
                                                        float* __restrict__ temb, float* __restrict__ temb_act) {
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const void* __restrict__ 
     float* h1 = sh + dim;       // [time_dim]
     const int b = blockIdx.x, tid = threadIdx.x;
     // t == nullptr: every tile shares the scalar step value (sampling loops)
+    if (sp) tval = sp->f[0];      // graph replay: the step's scalars live in device memory
     float tv = !t ? tval : (t_kind == 0) ? (float)reinterpret_cast<const long long*>(t)[b] : reinterpret_cast<const float*>(t)[b];
     const int half = dim / 2;
     for (int i = tid; i < dim; i += 256) {
@@ -141,10 +142,10 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(const void* __restrict__ 
     }
 }
 
-int launch_time_mlp(const void* t, int t_kind, float tval, int sr3, int Bt, int dim, int time_dim, const float* w1t, const float* b1,
+int launch_time_mlp(const void* t, int t_kind, float tval, const StepParams* sp, int sr3, int Bt, int dim, int time_dim, const float* w1t, const float* b1,
                     const float* w3t, const float* b3, float* temb, float* temb_act, hipStream_t st) {
     size_t lds = (size_t)(dim + time_dim) * sizeof(float);
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(Bt), dim3(256), lds, st, t, t_kind, tval, sr3, dim, time_dim, w1t, b1, w3t, b3, temb,
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(Bt), dim3(256), lds, st, t, t_kind, tval, sp, sr3, dim, time_dim, w1t, b1, w3t, b3, temb,
                        temb_act);
     return check_launch("time_mlp");
 }
@@ -586,9 +587,14 @@ int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uin
 __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x, const float* __restrict__ eps,
                                                           const float* __restrict__ noise, float c_recip, float c_recipm1,
                                                           float coef1, float coef2, float sigma, float* __restrict__ x0_out, int B,
-                                                          int SS4, uint64_t seed, uint64_t tile_off, uint32_t step) {
+                                                          int SS4, uint64_t seed, uint64_t tile_off, uint32_t step,
+                                                          const StepParams* __restrict__ sp) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * SS4) return;
+    if (sp) {
+        c_recip = sp->f[1]; c_recipm1 = sp->f[2]; coef1 = sp->f[3]; coef2 = sp->f[4]; sigma = sp->f[5];
+        seed = sp->seed; tile_off = sp->tile_off; step = sp->step;
+    }
     const float4 xv = reinterpret_cast<float4*>(x)[i];
     const float4 ev = reinterpret_cast<const float4*>(eps)[i];
     float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -607,11 +613,12 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
 }
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1, float coef2,
-                       float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st) {
+                       float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
+                       hipStream_t st) {
     if ((S * S) % 4) { hd_set_error("tile size must make S*S a multiple of 4"); return -1; }
     const int SS4 = S * S / 4;
     hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)(((size_t)B * SS4 + 255) / 256)), dim3(256), 0, st, x, eps, noise, c_recip,
-                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step);
+                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step, sp);
     return check_launch("ddpm_update");
 }
 
@@ -621,9 +628,15 @@ __global__ __launch_bounds__(256) void ddrm_update_kernel(float* __restrict__ x,
                                                           const float* __restrict__ y, const float* __restrict__ z, float sqrt_at,
                                                           float sqrt_1m_at, float sqrt_at_next, float sigma_next, float sigma_0,
                                                           float etaA, float etaB, float etaC, float* __restrict__ x0_out,
-                                                          size_t n, int SS, uint64_t seed, uint64_t tile_off, uint32_t step) {
+                                                          size_t n, int SS, uint64_t seed, uint64_t tile_off, uint32_t step,
+                                                          const StepParams* __restrict__ sp) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= n) return;
+    if (sp) {
+        sqrt_at = sp->f[1]; sqrt_1m_at = sp->f[2]; sqrt_at_next = sp->f[3]; sigma_next = sp->f[4]; sigma_0 = sp->f[5];
+        etaA = sp->f[6]; etaB = sp->f[7]; etaC = sp->f[8];
+        seed = sp->seed; tile_off = sp->tile_off; step = sp->step;
+    }
     const float4 xv = reinterpret_cast<float4*>(x)[i4];
     const float4 ev = reinterpret_cast<const float4*>(eps)[i4];
     const float4 yv = reinterpret_cast<const float4*>(y)[i4];
@@ -653,11 +666,11 @@ __global__ __launch_bounds__(256) void ddrm_update_kernel(float* __restrict__ x,
 
 int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
                        float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC, float* x0_out, int B,
-                       int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st) {
+                       int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp, hipStream_t st) {
     if ((S * S) % 4) { hd_set_error("tile size must make S*S a multiple of 4"); return -1; }
     const size_t n = (size_t)B * S * S;
     hipLaunchKernelGGL(ddrm_update_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, eps, y, z, sqrt_at, sqrt_1m_at,
-                       sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC, x0_out, n, S * S, seed, tile_off, step);
+                       sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC, x0_out, n, S * S, seed, tile_off, step, sp);
     return check_launch("ddrm_update");
 }
 
@@ -694,4 +707,13 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ pre
 int launch_loss(const float* pred, const float* target, int l2, float* out, int B, int S, hipStream_t st) {
     hipLaunchKernelGGL(loss_kernel, dim3(B), dim3(256), 0, st, pred, target, l2, out, S * S);
     return check_launch("loss");
+}
+
+// Writes one step's scalars into device memory ahead of a graph replay (kernel arguments are copied at
+// enqueue time, so the host may run arbitrarily far ahead of the device).
+__global__ void set_step_params_kernel(StepParams* dst, StepParams v) { *dst = v; }
+
+int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st) {
+    hipLaunchKernelGGL(set_step_params_kernel, dim3(1), dim3(1), 0, st, dst, v);
+    return check_launch("set_step_params");
 }

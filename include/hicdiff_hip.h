@@ -122,6 +122,12 @@ int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
 enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1 };
 int hd_set_precision(hd_ctx* ctx, int mode);
 
+/* hd_ddpm_step / hd_ddrm_step with device-generated noise replay a captured hipGraph of the whole step
+ * (one per (B, S, tensor addresses); the per-step scalars travel through a 1-thread kernel) on a
+ * stream owned by the context, ordered after/before the caller's stream by events.  0 disables it
+ * (every kernel is then launched eagerly on the caller's stream); env HICDIFF_GRAPHS=0|1 sets the default. */
+int hd_set_graphs(hd_ctx* ctx, int enable);
+
 /* ---- the hot path -------------------------------------------------------------------------- */
 
 /* eps = model(x, t, x_self_cond): Unet.forward src/hicdiff.py:345-387, hicedrn_Diff.forward
