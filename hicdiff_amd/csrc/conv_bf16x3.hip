@@ -20,6 +20,14 @@
 
 #include <set>
 
+// Diagnostic build (-DHD_STAMP): s_memtime stamps around the phases of the main loop; never quote its run
+// time, only the shares (cdna_hip_programming.md section 7, In-kernel stamps).
+#ifdef HD_STAMP
+#define STAMP(var) do { __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(var) do { } while (0)
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
@@ -97,6 +105,9 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
     const int ntaps = p.KH * p.KW, nchunks = p.Cin / CK, nit = ntaps * nchunks;
+    unsigned long long tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, tk4 = 0, acc_w = 0, acc_b = 0, acc_m = 0, acc_s = 0, t_begin = 0;
+    (void)tk0; (void)tk1; (void)tk2; (void)tk3; (void)tk4; (void)acc_w; (void)acc_b; (void)acc_m; (void)acc_s; (void)t_begin;
+    STAMP(t_begin);
     __syncthreads();                 // tables visible
 
     // per-thread staging items: item i = tid + 256*j = (pixel i / IPP, channels 8*(i % IPP)..+7).  256 is a
@@ -158,6 +169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 
     int buf = 0;
     for (int c = 0; c < nchunks; ++c) {
+        STAMP(tk4);
         if (c > 0) __syncthreads();      // every wave is done reading the previous slice's window
         // ---- stage slice c: transform + split + LDS write of the prefetched raw values
         if (!(p.ablate & 64)) {
@@ -177,21 +189,21 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
                 }
             }
         }
-        if (c + 1 < nchunks) {           // request the next slice's raw values now; they land during the taps
+        // The next slice's raw values are requested one item per tap, AFTER that tap's weight loads (below):
+        // vmcnt retires in issue order, so a wait for the weight slab never has to drain a younger, slower
+        // activation load, and every activation load gets about two tap iterations to land.
+        const float* nsrc = nullptr; int nCsrc = 0, ncoff = 0;
+        if (c + 1 < nchunks) {
             const int cc = (c + 1) * CK;
-            const float* src; int Csrc, coff;
-            if (cc < p.C0) { src = p.in0; Csrc = p.C0; coff = cc; } else { src = p.in1; Csrc = p.C1; coff = cc - p.C0; }
-#pragma unroll
-            for (int j = 0; j < MAXI; ++j) {
-                const float* g = src + (size_t)(it_src[j] < 0 ? 0 : it_src[j]) * Csrc + coff + q8;
-                if (!(p.ablate & 32)) {
-                    xr[j][0] = *reinterpret_cast<const float4*>(g);
-                    xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
-                }
-            }
+            if (cc < p.C0) { nsrc = p.in0; nCsrc = p.C0; ncoff = cc; } else { nsrc = p.in1; nCsrc = p.C1; ncoff = cc - p.C0; }
         }
+        STAMP(tk0);
+#ifdef HD_STAMP
+        acc_s += tk0 - tk4;
+#endif
         int ky = 0, kx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
+            STAMP(tk0);
             // weight slab (c, tap) -> LDS; prefetch the next slab into registers
             {
                 char* dst = Ws + buf * BN * PITCH;
@@ -202,8 +214,23 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
                     const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + ((size_t)(tapn * nchunks + cn) * p.CoutPad + t.n0) * ROWB;
                     HD_WLOAD(0) HD_WLOAD(1) HD_WLOAD(2) HD_WLOAD(3)
                 }
+                if (nsrc && !(p.ablate & 32)) {
+                    // items tap*IPT .. of the next slice (all remaining ones on the last tap)
+                    constexpr int IPT = (MAXI + 8) / 9;          // items per tap when there are 9 taps
+#pragma unroll
+                    for (int j = 0; j < MAXI; ++j) {
+                        const bool mine = (ntaps >= 9) ? (j / IPT == tap || (tap == ntaps - 1 && j / IPT >= ntaps)) : (tap == ntaps - 1);
+                        if (mine) {
+                            const float* g = nsrc + (size_t)(it_src[j] < 0 ? 0 : it_src[j]) * nCsrc + ncoff + q8;
+                            xr[j][0] = *reinterpret_cast<const float4*>(g);
+                            xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+                        }
+                    }
+                }
             }
+            STAMP(tk1);
             __syncthreads();             // X window (if just staged) and weight slab visible
+            STAMP(tk2);
             const char* Wb = Ws + buf * BN * PITCH;
             const int tapoff = (ky * p.LW + kx) * PITCH;
             if (!(p.ablate & 8))
@@ -231,6 +258,10 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
                     }
             }
+            STAMP(tk3);
+#ifdef HD_STAMP
+            acc_w += tk1 - tk0; acc_b += tk2 - tk1; acc_m += tk3 - tk2;
+#endif
             buf ^= 1;
             if (++kx == p.KW) { kx = 0; ++ky; }
         }
@@ -238,7 +269,15 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     (void)nit; (void)w1; (void)w2; (void)w3;
 #undef HD_WLOAD
 #undef HD_WSTORE
+    STAMP(tk0);
     conv_epilogue<BM, BN, TM, TN>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
+#ifdef HD_STAMP
+    STAMP(tk1);
+    if (p.stamp && t.lane == 0) {
+        atomicAdd(p.stamp + 0, acc_w); atomicAdd(p.stamp + 1, acc_b); atomicAdd(p.stamp + 2, acc_m); atomicAdd(p.stamp + 3, acc_s);
+        atomicAdd(p.stamp + 4, tk1 - tk0); atomicAdd(p.stamp + 5, tk1 - t_begin); atomicAdd(p.stamp + 6, 1ull); atomicAdd(p.stamp + 7, (unsigned long long)nit);
+    }
+#endif
 }
 
 template <typename K>

@@ -5,6 +5,7 @@
 #include "hd_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
     const float* in0; const float* in1;
@@ -18,6 +19,7 @@ struct ConvKArgs {
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     float* out; float* gn_part; int gn_slots;
+    unsigned long long* stamp;   // diagnostic build only (HD_STAMP): per-phase cycle sums, 8 counters
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };
 
@@ -37,7 +39,14 @@ __device__ __forceinline__ TileCtx tile_decode(const ConvKArgs& p) {
     t.tid = threadIdx.x; t.lane = t.tid & 63;
     const int wave = t.tid >> 6;
     t.wm = wave / WN; t.wn = wave % WN; t.half = t.lane >> 5; t.l31 = t.lane & 31;
+    // XCD-aware order: hardware deals workgroups round-robin over the 8 XCDs (private L2 each); remap so
+    // each XCD gets a CONTIGUOUS run of logical tiles -- the N-tiles of one M-tile and neighbouring
+    // M-tiles (shared halo rows, same weights) then share an L2.  Bijective: the tail keeps its index.
     int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, per = nwg >> 3;
+        if (bid < (per << 3)) bid = (bid & 7) * per + (bid >> 3);
+    }
     const int nt = bid % p.ntiles_n;
     int mt = bid / p.ntiles_n;
     t.tile_x = mt % p.tiles_x; mt /= p.tiles_x;
@@ -46,6 +55,18 @@ __device__ __forceinline__ TileCtx tile_decode(const ConvKArgs& p) {
     t.b0 = tile_b * p.TB; t.y0 = t.tile_y * p.TH; t.x0 = t.tile_x * p.TW; t.n0 = nt * BN;
     t.thw = p.TH * p.TW; t.mvalid = p.TB * t.thw;
     return t;
+}
+
+// GEMM row m -> output pixel (tb, ty, tx) of the tile.  Any bijection works as long as the operand reads and
+// the output table agree; when the window is 16 pixels wide, pixel row ty is rotated by ty*(LW-16) so that
+// the staged-pixel index of MFMA row r is congruent to r modulo 16: the 16 lanes of every ds_read_b128
+// group then hit 16 distinct 16-byte bank slots although a 32-row block spans two pixel rows.
+__device__ __forceinline__ void decode_row(const ConvKArgs& p, int thw, int m, int& tb, int& ty, int& tx) {
+    tb = m / thw;
+    const int r = m - tb * thw;
+    ty = r / p.TW;
+    tx = r - ty * p.TW;
+    if (p.TW == 16 && p.stride == 1) tx = (tx - ty * (p.LW - 16)) & 15;
 }
 
 // pxsrc[i]: linear index of the stored input pixel feeding staged pixel i (or -1: zero padding /
@@ -71,9 +92,8 @@ __device__ __forceinline__ void init_tables(const ConvKArgs& p, const TileCtx& t
         pxb[i] = b < p.B ? b : p.B - 1;
     }
     for (int m = t.tid; m < BM; m += 256) {
-        int tb = m / t.thw;
-        int r = m - tb * t.thw;
-        int ty = r / p.TW, tx = r - ty * p.TW;
+        int tb, ty, tx;
+        decode_row(p, t.thw, m, tb, ty, tx);
         int b = t.b0 + tb, y = t.y0 + ty, x = t.x0 + tx;
         bool v = (m < t.mvalid) && b < p.B && y < p.H && x < p.W;
         rowpix[m] = v ? (b * p.H + y) * p.W + x : -1;
@@ -86,9 +106,8 @@ template <int TM>
 __device__ __forceinline__ int row_px_offset(const ConvKArgs& p, const TileCtx& t, int tm) {
     int m = t.wm * 32 * TM + tm * 32 + t.l31;
     if (m >= t.mvalid) m = 0;
-    int tb = m / t.thw;
-    int r = m - tb * t.thw;
-    int ty = r / p.TW, tx = r - ty * p.TW;
+    int tb, ty, tx;
+    decode_row(p, t.thw, m, tb, ty, tx);
     return (tb * p.LH + ty * p.stride) * p.LW + tx * p.stride;
 }
 
@@ -122,20 +141,9 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 template <int BM, int BN, int TM, int TN>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
                                               const int* rowb, float* stage) {
-    constexpr int EP = BN + 4, CQ = BN / 4, RPP = 256 / CQ, NPASS = BM / RPP;
-    __syncthreads();                       // every wave has finished reading the last tap's operands
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = t.wn * 32 * TN + tn * 32 + t.l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = t.wm * 32 * TM + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;
-                stage[m * EP + col] = acc[tm][tn][r];
-            }
-        }
-    __syncthreads();
+    // The tile is staged in TM rounds of BM/TM rows (round tm holds, for every wave-row wm, its rows
+    // tm*32..tm*32+31), so the staging area is BM/TM x (BN+4) floats and does not set the LDS footprint.
+    constexpr int EP = BN + 4, CQ = BN / 4, RPP = 256 / CQ, RB = BM / TM, NPASS = RB / RPP, WMN = BM / (32 * TM);
     const int cq = t.tid % CQ, rg = t.tid / CQ;
     const int n = t.n0 + cq * 4;
     const int nvalid = p.Cout - n;         // >= 4: all four channels of this thread exist
@@ -146,62 +154,80 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         for (int j = 0; j < 4; ++j) if (j < nvalid) bias[j] = p.bias[n + j];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nvalid > 0 && !(p.ablate & 128)) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        __syncthreads();                   // operands (tm == 0) / previous round's rows are no longer read
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int col = t.wn * 32 * TN + tn * 32 + t.l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lr = t.wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;    // row inside this round
+                stage[lr * EP + col] = acc[tm][tn][r];
+            }
+        }
+        __syncthreads();
+        if (nvalid > 0 && !(p.ablate & 128)) {
 #pragma unroll 4
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int m = pass * RPP + rg;
-            const int pix = rowpix[m];
-            if (pix < 0) continue;
-            const float4 a4 = *reinterpret_cast<const float4*>(stage + m * EP + cq * 4);
-            float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int lr = pass * RPP + rg;                                     // = wm*32 + row in the 32-row block
+                const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
+                const int pix = rowpix[m];
+                if (pix < 0) continue;
+                const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-            const size_t o = (size_t)pix * p.Cout + n;
-            if (vec) {
-                if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
-                    const int fo = rowb[m] * p.ep_bstride + n;
-                    const float4 sh = *reinterpret_cast<const float4*>(p.epShift + fo);
-                    if (p.ep & EP_FILM_SILU) {
-                        const float4 sc = *reinterpret_cast<const float4*>(p.epScale + fo);
-                        v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
-                        v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;
-                    } else { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
-                }
-                if (p.ep & EP_RES) {
-                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
-                    v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w;
-                }
-                if (p.ep & EP_RES_AFFINE_SILU) {
-                    const int fo = rowb[m] * p.res_bstride + n;
-                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
-                    const float4 ra = *reinterpret_cast<const float4*>(p.resA + fo);
-                    const float4 rb = *reinterpret_cast<const float4*>(p.resB + fo);
-                    v[0] += silu_f(rr.x * ra.x + rb.x); v[1] += silu_f(rr.y * ra.y + rb.y);
-                    v[2] += silu_f(rr.z * ra.z + rb.z); v[3] += silu_f(rr.w * ra.w + rb.w);
-                }
-                if (!(p.ablate & 1) || v[0] == 123456.789f) *reinterpret_cast<float4*>(p.out + o) = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (j >= nvalid) break;
-                    float x = v[j];
+                for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+                const size_t o = (size_t)pix * p.Cout + n;
+                if (vec) {
                     if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
-                        const int fo = rowb[m] * p.ep_bstride + n + j;
-                        x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
-                        x = silu_f(x);
+                        const int fo = rowb[m] * p.ep_bstride + n;
+                        const float4 sh = *reinterpret_cast<const float4*>(p.epShift + fo);
+                        if (p.ep & EP_FILM_SILU) {
+                            const float4 sc = *reinterpret_cast<const float4*>(p.epScale + fo);
+                            v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
+                            v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;
+                        } else { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
                     }
-                    if (p.ep & EP_RES) x = p.alpha * x + p.res[o + j];
+                    if (p.ep & EP_RES) {
+                        const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                        v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w;
+                    }
                     if (p.ep & EP_RES_AFFINE_SILU) {
-                        const int fo = rowb[m] * p.res_bstride + n + j;
-                        x += silu_f(p.res[o + j] * p.resA[fo] + p.resB[fo]);
+                        const int fo = rowb[m] * p.res_bstride + n;
+                        const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                        const float4 ra = *reinterpret_cast<const float4*>(p.resA + fo);
+                        const float4 rb = *reinterpret_cast<const float4*>(p.resB + fo);
+                        v[0] += silu_f(rr.x * ra.x + rb.x); v[1] += silu_f(rr.y * ra.y + rb.y);
+                        v[2] += silu_f(rr.z * ra.z + rb.z); v[3] += silu_f(rr.w * ra.w + rb.w);
                     }
-                    p.out[o + j] = x;
+                    const f32x4 o4 = {v[0], v[1], v[2], v[3]};
+                    if (p.ablate & 512) __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(p.out + o));
+                    else if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + o) = o4;      // one 16-byte store per lane
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (j >= nvalid) break;
+                        float x = v[j];
+                        if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                            const int fo = rowb[m] * p.ep_bstride + n + j;
+                            x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
+                            x = silu_f(x);
+                        }
+                        if (p.ep & EP_RES) x = p.alpha * x + p.res[o + j];
+                        if (p.ep & EP_RES_AFFINE_SILU) {
+                            const int fo = rowb[m] * p.res_bstride + n + j;
+                            x += silu_f(p.res[o + j] * p.resA[fo] + p.resB[fo]);
+                        }
+                        p.out[o + j] = x;
+                    }
                 }
             }
         }
     }
+    (void)WMN;
     if (p.gn_part) {   // TB == 1: every row of this workgroup belongs to sample b0
         __syncthreads();                   // stage is free again: reuse it as [RPP][BN][2]
         float* red = stage;

@@ -67,6 +67,9 @@ void conv_prof_end(hipStream_t st) {
     g_prof.push_back(g_cur);
 }
 
+// diagnostic build: device buffer of 8 phase counters (hd_debug_stamp_* in engine.hip)
+unsigned long long* g_stamp = nullptr;
+
 // ---- tile planning ---------------------------------------------------------------------------------
 struct TileGeom { int TB, TH, TW; };
 
@@ -125,7 +128,7 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
     const int LH = (pl.g.TH - 1) * a.stride + a.cw.KH, LW = (pl.g.TW - 1) * a.stride + a.cw.KW;
     const int npx = pl.g.TB * LH * LW, npx4 = (npx + 3) & ~3;
-    const size_t stage = (size_t)pl.BM * (pl.BN + 4) * 4;      // epilogue staging overlays the operand buffers
+    const size_t stage = (size_t)(pl.BM / 2) * (pl.BN + 4) * 4;  // epilogue staging (TM = 2 rounds) overlays the operand buffers
     pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(wbytes + (size_t)npx * pl.pitch, stage);
     return pl;
 }
@@ -150,6 +153,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.out = a.out;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
+    k.stamp = g_stamp;
     const ConvPlan pl = plan_conv(a);
     if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
         hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");

@@ -616,6 +616,7 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->cin0 = a->self_condition ? 2 : 1;
     c->time_in = a->dim; c->time_dim = a->dim * 4;
     c->ck = (a->dim % 32 == 0) ? 32 : 16;
+    if (const char* k = getenv("HICDIFF_CK")) { if (atoi(k) == 16) c->ck = 16; }   // tuning experiments
     if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0;
     if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
@@ -810,6 +811,22 @@ int hd_profile_read(hd_profile_row rows[HD_PROFILE_ROWS]) {
 }
 
 // ---- test-only entry points (include/hicdiff_hip_debug.h) ----
+}  // extern "C"
+extern unsigned long long* g_stamp;
+extern "C" {
+int hd_debug_stamp(int enable, unsigned long long out[8]) {
+    if (enable == 1) {
+        if (!g_stamp && hipMalloc((void**)&g_stamp, 64) != hipSuccess) return HD_EHIP;
+        (void)hipMemset(g_stamp, 0, 64);
+        return HD_OK;
+    }
+    if (!g_stamp || !out) return HD_EINVAL;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, g_stamp, 64, hipMemcpyDeviceToHost);
+    if (enable == 0) { (void)hipFree(g_stamp); g_stamp = nullptr; }
+    return HD_OK;
+}
+
 int hd_debug_capture(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
     c->capture = enable != 0;
