@@ -1,4 +1,8 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -4
-python bench.py --warmup 3 --steps 10 2>&1 | tail -1 > gpurun_out/bench5.json; cut -c1-700 gpurun_out/bench5.json
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/r01b_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01b_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01b_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b_hicedrn -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload hicedrn64 > $R/gpurun_out/r01b_hicedrn.log 2>&1
+ls $R/gpurun_out/r01b_*/*/ | head -20
