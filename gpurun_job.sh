@@ -1,8 +1,6 @@
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b_stats -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/r01b_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/r01b_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/r01b_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r01b_hicedrn -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload hicedrn64 > $R/gpurun_out/r01b_hicedrn.log 2>&1
-ls $R/gpurun_out/r01b_*/*/ | head -20
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python -m pytest tests/test_gpu_parity.py -m gpu -q -x 2>&1 | tail -5
+python bench.py --warmup 3 --steps 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import sys, json
+d=json.loads(sys.stdin.readline()); print('unet64 ms_per_step', d['ms_per_step'], 'tiles/s', d['value'], 'frac', d['roofline']['frac'], 'conv share', d['roofline']['conv_time_share'])"

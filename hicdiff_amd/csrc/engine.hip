@@ -80,6 +80,9 @@ struct ResW {
 struct AttnW {
     float* norm_g = nullptr; float* out_g = nullptr;
     ConvW qkv, out;
+    ConvW qonly;                       // fused path: q = to_qkv[0:128] only
+    unsigned short* wkv = nullptr;     // fused path: split k/v weight image with the LayerNorm gain folded in
+    bool fused = false;
     int dim = 0; bool linear = true;
     std::string name;
 };
@@ -211,6 +214,21 @@ static int load_attn(Loader& L, const std::string& p, int dim, bool linear, Attn
     a->name = p; a->dim = dim; a->linear = linear;
     HD_TRY(L.vec(p + ".fn.norm.g", {1, dim, 1, 1}, &a->norm_g));
     HD_TRY(L.conv(p + ".fn.fn.to_qkv", 384, dim, 1, false, false, false, &a->qkv));
+    if (linear && dim == 64) {
+        // fused key/value side (linattn_fused.hip): q-only projection + packed k/v weights
+        const hd_named_tensor* t = L.get(p + ".fn.fn.to_qkv.weight", {384, dim, 1, 1});
+        if (!t) return HD_ENOWEIGHT;
+        hd_ctx* c = L.c;
+        ConvW& q = a->qonly;
+        q.KH = q.KW = 1; q.Cin = dim; q.Cout = 128; q.CoutPad = 128; q.ck = (dim % c->ck == 0) ? c->ck : 16;
+        if (!q.w) { q.w = L.dev((size_t)dim * 128); if (!q.w) return HD_EHIP; }
+        HD_TRY(launch_pack_conv((const float*)t->data, q.w, 128, dim, 1, 1, 128, 0, 0, L.st));
+        if (!q.wsplit) { q.wsplit = (unsigned short*)L.dev((size_t)dim * 128); if (!q.wsplit) return HD_EHIP; }   // 2 shorts per weight
+        HD_TRY(launch_split_conv(q.w, q.wsplit, 1, dim, 128, q.ck, L.st));
+        if (!a->wkv) { a->wkv = (unsigned short*)L.dev((size_t)256 * dim); if (!a->wkv) return HD_EHIP; }
+        HD_TRY(launch_pack_kv((const float*)t->data, a->norm_g, dim, a->wkv, L.st));
+        a->fused = true;
+    }
     if (linear) {
         HD_TRY(L.conv(p + ".fn.fn.to_out.0", dim, 128, 1, false, false, true, &a->out));
         HD_TRY(L.vec(p + ".fn.fn.to_out.1.g", {1, dim, 1, 1}, &a->out_g));
@@ -410,19 +428,34 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
     const size_t P = x.pixels();
     float* stats; HD_TRY(r.alloc(P * 2, &stats));
     if (!r.dry) HD_TRY(launch_ln_stats(x.p, P, C, stats, r.st));
-    Act qkv; HD_TRY(r.act(H, W, 384, &qkv));
+    const bool fused = w.linear && w.fused && r.c->precision == HD_PREC_BF16X3;
+    // the dry run sizes the workspace for either arithmetic mode (hd_set_precision may switch later)
+    Act qkv; HD_TRY(r.act(H, W, (fused && !r.dry) ? 128 : 384, &qkv));
     ConvArgs q;
-    q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = w.qkv; q.out = qkv.p;
+    q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = fused ? w.qonly : w.qkv; q.out = qkv.p;
     q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
     HD_TRY(run_conv(r, q));
     r.free(stats);
     Act att; HD_TRY(r.act(H, W, 128, &att));
-    if (w.linear) {
+    if (fused) {
+        const int nsplit = linattn_kv_nsplit(HW);
+        const size_t slots = (size_t)r.B * heads * nsplit;
+        float *ctx, *scr;
+        HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
+        HD_TRY(r.alloc(std::max(slots * (32 + 32 + 32 * 32), linattn_scratch_floats(r.B, HW, heads)), &scr));
+        if (!r.dry) {
+            float* pmax = scr; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
+            HD_TRY(launch_linattn_kv_fused(x.p, w.wkv, r.B, HW, C, pmax, psum, pctx, r.st));
+            HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nsplit, HW, ctx, r.st));
+            HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st));
+        }
+        r.free(ctx); r.free(scr);
+    } else if (w.linear) {
         float* ctx; HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
-        float* scr; HD_TRY(r.alloc(linattn_scratch_floats(r.B, HW, heads), &scr));
+        float* scr; HD_TRY(r.alloc(std::max(linattn_scratch_floats(r.B, HW, heads), (size_t)r.B * heads * linattn_kv_nsplit(HW) * (32 + 32 + 32 * 32)), &scr));
         if (!r.dry) {
             HD_TRY(launch_linattn_context(qkv.p, r.B, HW, heads, scr, ctx, r.st));
-            HD_TRY(launch_linattn_apply(qkv.p, ctx, r.B, HW, heads, att.p, r.st));
+            HD_TRY(launch_linattn_apply(qkv.p, 384, ctx, r.B, HW, heads, att.p, r.st));
         }
         r.free(ctx); r.free(scr);
     } else if (!r.dry) {

@@ -107,7 +107,13 @@ int launch_ln_stats(const float* x, size_t P, int C, float* stats, hipStream_t s
 int launch_ln_residual(const float* y, const float* g, const float* res, float* out, size_t P, int C, hipStream_t st);
 size_t linattn_scratch_floats(int B, int HW, int heads);
 int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* scratch, float* ctx, hipStream_t st);
-int launch_linattn_apply(const float* qkv, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st);
+int launch_linattn_apply(const float* qkv, int qstride, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st);
+int launch_linattn_combine(const float* pmax, const float* psum, const float* pctx, int B, int heads, int nsplit, int HW, float* ctx,
+                           hipStream_t st);
+int launch_pack_kv(const float* wqkv, const float* g, int C, unsigned short* dst, hipStream_t st);
+int linattn_kv_nsplit(int HW);
+int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
+                            hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,

@@ -1,0 +1,223 @@
+// Fused key/value side of LinearAttention (src/hicdiff.py:212-223) for 64-channel feature maps:
+//
+//   LN(x) -> k, v = to_qkv[128:384](LN(x)) -> softmax_n(k) -> context[d][e] = sum_n softmax(k)[d][n] v[e][n] / HW
+//
+// One workgroup per (sample, 64-token chunk); k and v are never written to HBM (the unfused path wrote a
+// 384-channel qkv tensor -- 1.6 GB at B=256, S=64 -- and read two thirds of it back).  Wave w owns head
+// w: it multiplies the shared LN'd token tile [64][C] by that head's 64 weight rows (32 k + 32 v) on the
+// split-bf16 MFMA path; the accumulators then hold k and v with the token on the REGISTER index and the
+// channel on the lane, so the column softmax statistics are in-lane reductions, and the context product,
+// which sums over tokens, takes both accumulator tiles directly as MFMA operands (both operands share
+// the accumulator layout's k-order, so no lane movement and no LDS round trip).  Each chunk emits
+// flash-style partials (column maxima, exp-sums, un-normalised 32x32 context); linattn_combine_kernel
+// rescales and normalises them in a fixed order.
+#include "hd_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define KV_TOK 64
+
+__device__ __forceinline__ void split8v(const float (&v)[8], uint4& hi, uint4& lo) {
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hh = (__bf16)v[j];
+        const __bf16 ll = (__bf16)(v[j] - (float)hh);
+        h[j] = __builtin_bit_cast(unsigned short, hh);
+        l[j] = __builtin_bit_cast(unsigned short, ll);
+    }
+    hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+}
+
+// eight consecutive accumulator registers (rows of a 32x32 tile) -> bf16 hi / lo operand fragments
+__device__ __forceinline__ void acc_to_frag(const f32x16& a, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = a[8 * s + j];
+        const __bf16 hh = (__bf16)v;
+        hi[j] = hh;
+        lo[j] = (__bf16)(v - (float)hh);
+    }
+}
+
+// wkv: [C/32 slices][256 rows = head*64 + {k: 0..31, v: 32..63}][32 bf16 hi | 32 bf16 lo], LayerNorm gain folded in.
+template <int C>
+__global__ __launch_bounds__(256) void linattn_kv_fused_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wkv,
+                                                               int HW, int nsplit, float* __restrict__ pmax,
+                                                               float* __restrict__ psum, float* __restrict__ pctx) {
+    constexpr int CK = 32, PITCH = 4 * CK + 16, ROWB = 4 * CK, NS = C / CK, heads = 4, D = 32;
+    constexpr int QPT = C / 4 / 4;                     // float4 per thread: 4 threads share a token
+    __shared__ __attribute__((aligned(16))) char Xs[KV_TOK * PITCH];
+    __shared__ __attribute__((aligned(16))) char Ws[256 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    const int n0 = sp * KV_TOK, ntok = min(KV_TOK, HW - n0);
+
+    // ---- LayerNorm of the token rows (4 threads per token, the row stays in registers)
+    const int tok = tid >> 2, part = tid & 3;
+    const bool tvalid = tok < ntok;
+    const float* row = x + ((size_t)b * HW + n0 + (tvalid ? tok : 0)) * C + part * (C / 4);
+    float4 xv[QPT];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) { xv[j] = reinterpret_cast<const float4*>(row)[j]; s += xv[j].x + xv[j].y + xv[j].z + xv[j].w; }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const float a0 = xv[j].x - mean, a1 = xv[j].y - mean, a2 = xv[j].z - mean, a3 = xv[j].w - mean;
+        q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+    }
+    q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+    const float rstd = 1.f / sqrtf(q / C + 1e-5f);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int sl = 0; sl < NS; ++sl) {
+        if (sl > 0) __syncthreads();
+        // stage the K slice of the normalised tile: the thread's C/4 channels start at part*C/4
+        {
+            constexpr int CPT = C / 4;                         // channels per thread
+#pragma unroll
+            for (int g8 = 0; g8 < CPT / 8; ++g8) {
+                const int c0 = part * CPT + g8 * 8;            // global channel of this group of 8
+                if (c0 / CK == sl) {
+                    const float4 a = xv[2 * g8], bq = xv[2 * g8 + 1];
+                    float v[8] = {(a.x - mean) * rstd, (a.y - mean) * rstd, (a.z - mean) * rstd, (a.w - mean) * rstd,
+                                  (bq.x - mean) * rstd, (bq.y - mean) * rstd, (bq.z - mean) * rstd, (bq.w - mean) * rstd};
+                    uint4 hi, lo;
+                    split8v(v, hi, lo);
+                    if (!tvalid) { hi = make_uint4(0, 0, 0, 0); lo = hi; }
+                    char* d = Xs + tok * PITCH + (c0 - sl * CK) * 2;
+                    *reinterpret_cast<uint4*>(d) = hi;
+                    *reinterpret_cast<uint4*>(d + 2 * CK) = lo;
+                }
+            }
+        }
+        // weight slab of this slice: 256 rows x 128 B
+        {
+            const char* src = reinterpret_cast<const char*>(wkv) + (size_t)sl * 256 * ROWB;
+#pragma unroll
+            for (int j = 0; j < (256 * (CK / 4)) / 256; ++j) {
+                const int idx = tid + j * 256;
+                const int r = idx / (CK / 4), piece = idx - r * (CK / 4);
+                *reinterpret_cast<uint4*>(Ws + r * PITCH + piece * 16) = *reinterpret_cast<const uint4*>(src + (size_t)r * ROWB + piece * 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm) {
+                const char* a = Xs + (tm * 32 + l31) * PITCH + half * 16 + ks * 32;
+                ah[tm] = *reinterpret_cast<const bf16x8*>(a);
+                al[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
+            }
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const char* bp = Ws + (w * 64 + tn * 32 + l31) * PITCH + half * 16 + ks * 32;
+                bh[tn] = *reinterpret_cast<const bf16x8*>(bp);
+                bl[tn] = *reinterpret_cast<const bf16x8*>(bp + 2 * CK);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- column softmax statistics of k over the chunk's tokens (rows = registers), p = exp(k - max)
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (t < ntok) mx = fmaxf(mx, acc[tm][0][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float ps = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float pe = t < ntok ? __expf(acc[tm][0][r] - mx) : 0.f;
+            acc[tm][0][r] = pe;
+            ps += pe;
+            if (t >= ntok) acc[tm][1][r] = 0.f;                // v of tokens past the end
+        }
+    ps += __shfl_xor(ps, 32);
+
+    // ---- context[d][e] = sum_tok p[tok][d] * v[tok][e]: both tiles feed the MFMA straight from the accumulators
+    f32x16 ctx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ph, pl, vh, vl;
+            acc_to_frag(acc[tm][0], s2, ph, pl);
+            acc_to_frag(acc[tm][1], s2, vh, vl);
+            ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, vh, ctx, 0, 0, 0);
+            ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vl, ctx, 0, 0, 0);
+            ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vh, ctx, 0, 0, 0);
+        }
+
+    const size_t slot = ((size_t)b * heads + w) * nsplit + sp;
+    if (half == 0) { pmax[slot * D + l31] = mx; psum[slot * D + l31] = ps; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D layout: row = d, column (lane) = e
+        pctx[(slot * D + d) * D + l31] = ctx[r];
+    }
+}
+
+// to_qkv weight [384][C] (torch) + LayerNorm gain g[C] -> the kernel's split k/v image
+__global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ wqkv, const float* __restrict__ g, int C,
+                                                      unsigned short* __restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;        // over 256 rows x C
+    if (i >= 256 * C) return;
+    const int r = i / C, c = i - r * C;
+    const int h = r / 64, j = r - h * 64;
+    const int src_row = j < 32 ? 128 + h * 32 + j : 256 + h * 32 + (j - 32);   // k block, v block of to_qkv
+    const float v = wqkv[(size_t)src_row * C + c] * g[c];
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const int sl = c / 32, kl = c - sl * 32;
+    unsigned short* row = dst + ((size_t)sl * 256 + r) * 64;
+    row[kl] = __builtin_bit_cast(unsigned short, hi);
+    row[32 + kl] = __builtin_bit_cast(unsigned short, lo);
+}
+
+int launch_pack_kv(const float* wqkv, const float* g, int C, unsigned short* dst, hipStream_t st) {
+    hipLaunchKernelGGL(pack_kv_kernel, dim3((256 * C + 255) / 256), dim3(256), 0, st, wqkv, g, C, dst);
+    return 0;
+}
+
+int linattn_kv_nsplit(int HW) { return (HW + KV_TOK - 1) / KV_TOK; }
+
+int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
+                            hipStream_t st) {
+    if (C != 64) { hd_set_error("linattn_kv_fused: only 64-channel maps"); return -1; }
+    const int nsplit = linattn_kv_nsplit(HW);
+    hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, dim3((unsigned)(B * nsplit)), dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hd_set_error(std::string("linattn_kv_fused: ") + hipGetErrorString(e)); return -3; }
+    return 0;
+}

@@ -426,6 +426,12 @@ __global__ __launch_bounds__(256) void linattn_combine_kernel(const float* __res
     *reinterpret_cast<float4*>(ctx + ((size_t)bh * D + dd) * D + e0) = make_float4(a0 * inv, a1 * inv, a2 * inv, a3 * inv);
 }
 
+int launch_linattn_combine(const float* pmax, const float* psum, const float* pctx, int B, int heads, int nsplit, int HW, float* ctx,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(linattn_combine_kernel, dim3(B * heads), dim3(256), 0, st, pmax, psum, pctx, nsplit, HW, ctx);
+    return check_launch("linattn_combine");
+}
+
 size_t linattn_scratch_floats(int B, int HW, int heads) {
     const int nsplit = (HW + LINATTN_SPLIT - 1) / LINATTN_SPLIT;
     return (size_t)B * heads * nsplit * (32 + 32 + 32 * 32);
@@ -441,7 +447,7 @@ int launch_linattn_context(const float* qkv, int B, int HW, int heads, float* sc
 }
 
 //   out[n][h*32+e] = scale * sum_d context[d][e] * softmax_d(q[:, n])[d]    (one thread per (pixel, head))
-__global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ctx,
+__global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ qkv, int qstride, const float* __restrict__ ctx,
                                                             int HW, int heads, float* __restrict__ out) {
     constexpr int D = 32;
     __shared__ float cs[D][D];
@@ -452,8 +458,7 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
     __syncthreads();
     const int n = chunk * 256 + tid;
     if (n >= HW) return;
-    const int C3 = 3 * heads * D;
-    const float* q = qkv + ((size_t)b * HW + n) * C3 + h * D;
+    const float* q = qkv + ((size_t)b * HW + n) * qstride + h * D;     // qstride: 384 (qkv tensor) or 128 (q only)
     float qv[D];
     float mx = -3.0e38f;
 #pragma unroll
@@ -479,9 +484,9 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
     }
 }
 
-int launch_linattn_apply(const float* qkv, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st) {
+int launch_linattn_apply(const float* qkv, int qstride, const float* ctx, int B, int HW, int heads, float* out, hipStream_t st) {
     const int chunks = (HW + 255) / 256;
-    hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * heads * chunks), dim3(256), 0, st, qkv, ctx, HW, heads, out);
+    hipLaunchKernelGGL(linattn_apply_kernel, dim3(B * heads * chunks), dim3(256), 0, st, qkv, qstride, ctx, HW, heads, out);
     return check_launch("linattn_apply");
 }
 
