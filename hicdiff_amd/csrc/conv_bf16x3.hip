@@ -70,12 +70,13 @@ __device__ __forceinline__ float4 xform4(const ConvKArgs& p, float4 v, int cc, i
 
 // WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread.
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+    constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = 4 * CK + 16, ROWB = 4 * CK;
     constexpr int KS = CK / 16;                        // k16 MFMA steps per slab
     constexpr int IPP = CK / 8;                        // 8-channel items per staged pixel
-    constexpr int NW = (BN * (CK / 4)) / 256;          // 16-byte weight pieces per thread per slab
-    static_assert(NW >= 1 && WM * WN == 4, "bad tile");
+    constexpr int NW = (BN * (CK / 4)) / NT;           // 16-byte weight pieces per thread per slab
+    static_assert(NW >= 1 && (NT == 256 || NT == 512), "bad tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int npx = p.npx;
     const int npx4 = (npx + 3) & ~3;
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
-    init_tables<BM>(p, t, pxsrc, pxb, rowpix, rowb);
+    init_tables<BM, NT>(p, t, pxsrc, pxb, rowpix, rowb);
 
     int aoff[TM], boff[TN];
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     // PXSTEP apart.  Source indices are clamped so every lane issues every load (no divergent control flow
     // around memory operations); padding pixels (src < 0) and items past the window are neutralised when
     // the LDS rows are written.
-    constexpr int PXSTEP = 256 / IPP;
+    constexpr int PXSTEP = NT / IPP;
     const int q8 = (tid % IPP) * 8, px0 = tid / IPP;
     int it_src[MAXI], it_aff[MAXI];
 #pragma unroll
@@ -140,13 +141,13 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     static_assert(NW <= 4, "weight slab prefetch holds at most four 16-byte pieces per thread");
 #define HD_WLOAD(k)                                                                                        \
     if constexpr (NW > k) {                                                                                \
-        const int idx = tid + k * 256;                                                                     \
+        const int idx = tid + k * NT;                                                                      \
         const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
         w##k = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * ROWB + piece * 16);                    \
     }
 #define HD_WSTORE(k)                                                                                       \
     if constexpr (NW > k) {                                                                                \
-        const int idx = tid + k * 256;                                                                     \
+        const int idx = tid + k * NT;                                                                      \
         const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
         *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = w##k;                                  \
     }
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 #undef HD_WLOAD
 #undef HD_WSTORE
     STAMP(tk0);
-    conv_epilogue<BM, BN, TM, TN>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
+    conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
 #ifdef HD_STAMP
     STAMP(tk1);
     if (p.stamp && t.lane == 0) {
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
 }
 
 template <typename K>
-static int launch_one(K kernel, ConvLaunch& L, hipStream_t st) {
+static int launch_one(K kernel, ConvLaunch& L, hipStream_t st, int nthreads = 256) {
     static std::set<const void*> raised;   // every instantiation has the same pointer TYPE: key by address
     if (!raised.count(reinterpret_cast<const void*>(kernel))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -293,7 +294,7 @@ static int launch_one(K kernel, ConvLaunch& L, hipStream_t st) {
     const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
     dim3 grid((unsigned)(mtiles * k.ntiles_n));
     conv_prof_begin(L, st);
-    hipLaunchKernelGGL(kernel, grid, dim3(256), L.lds, st, L.k);
+    hipLaunchKernelGGL(kernel, grid, dim3(nthreads), L.lds, st, L.k);
     conv_prof_end(st);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hd_set_error(std::string("conv launch: ") + hipGetErrorString(e)); return -3; }
@@ -306,10 +307,12 @@ static int launch_mode(ConvLaunch& L, hipStream_t st) {
     if (L.ck == 32) {
         if (L.cfg == 0) return launch_one(conv_igemm_bf16x3_kernel<2, 2, 2, 2, 32, 5, MODE>, L, st);
         if (L.cfg == 1) return launch_one(conv_igemm_bf16x3_kernel<2, 2, 2, 1, 32, 5, MODE>, L, st);
+        if (L.cfg == 3) return launch_one(conv_igemm_bf16x3_kernel<4, 2, 2, 2, 32, 3, MODE>, L, st, 512);
         return launch_one(conv_igemm_bf16x3_kernel<4, 1, 2, 2, 32, 6, MODE>, L, st);
     }
     if (L.cfg == 0) return launch_one(conv_igemm_bf16x3_kernel<2, 2, 2, 2, 16, 3, MODE>, L, st);
     if (L.cfg == 1) return launch_one(conv_igemm_bf16x3_kernel<2, 2, 2, 1, 16, 3, MODE>, L, st);
+    if (L.cfg == 3) return launch_one(conv_igemm_bf16x3_kernel<4, 2, 2, 2, 16, 2, MODE>, L, st, 512);
     return launch_one(conv_igemm_bf16x3_kernel<4, 1, 2, 2, 16, 3, MODE>, L, st);
 }
 

@@ -71,10 +71,10 @@ __device__ __forceinline__ void decode_row(const ConvKArgs& p, int thw, int m, i
 
 // pxsrc[i]: linear index of the stored input pixel feeding staged pixel i (or -1: zero padding /
 // outside the batch); rowpix[m]: linear output pixel of GEMM row m (or -1).
-template <int BM>
+template <int BM, int NT>
 __device__ __forceinline__ void init_tables(const ConvKArgs& p, const TileCtx& t, int* pxsrc, int* pxb, int* rowpix, int* rowb) {
     const int LH = p.LH, LW = p.LW;
-    for (int i = t.tid; i < p.npx; i += 256) {
+    for (int i = t.tid; i < p.npx; i += NT) {
         int tb = i / (LH * LW);
         int r = i - tb * LH * LW;
         int ly = r / LW, lx = r - ly * LW;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void init_tables(const ConvKArgs& p, const TileCtx& t
         pxsrc[i] = src;
         pxb[i] = b < p.B ? b : p.B - 1;
     }
-    for (int m = t.tid; m < BM; m += 256) {
+    for (int m = t.tid; m < BM; m += NT) {
         int tb, ty, tx;
         decode_row(p, t.thw, m, tb, ty, tx);
         int b = t.b0 + tb, y = t.y0 + ty, x = t.x0 + tx;
@@ -138,12 +138,12 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 //   stage: LDS, BM x (BN + 4) floats, overlays the operand buffers (all MFMA reads are done).
 //   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
 //   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
-template <int BM, int BN, int TM, int TN>
+template <int BM, int BN, int TM, int TN, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
                                               const int* rowb, float* stage) {
     // The tile is staged in TM rounds of BM/TM rows (round tm holds, for every wave-row wm, its rows
     // tm*32..tm*32+31), so the staging area is BM/TM x (BN+4) floats and does not set the LDS footprint.
-    constexpr int EP = BN + 4, CQ = BN / 4, RPP = 256 / CQ, RB = BM / TM, NPASS = RB / RPP, WMN = BM / (32 * TM);
+    constexpr int EP = BN + 4, CQ = BN / 4, RPP = NT / CQ, RB = BM / TM, NPASS = RB / RPP, WMN = BM / (32 * TM);
     const int cq = t.tid % CQ, rg = t.tid / CQ;
     const int n = t.n0 + cq * 4;
     const int nvalid = p.Cout - n;         // >= 4: all four channels of this thread exist
@@ -250,7 +250,7 @@ struct ConvLaunch {
     size_t lds;
     int variant;     // profiler row
     int ck;          // K slice
-    int cfg;         // 0: 128 x 128 tile (waves 2 x 2), 1: 128 x 64 (2 x 2), 2: 256 x 64 (4 x 1)
+    int cfg;         // 0: 128 x 128 tile (waves 2 x 2), 1: 128 x 64 (2 x 2), 2: 256 x 64 (4 x 1), 3: 256 x 128 (8 waves, 4 x 2)
 };
 int launch_conv_f32(ConvLaunch& L, hipStream_t st);
 int launch_conv_bf16x3(ConvLaunch& L, hipStream_t st);

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvKArgs p) {
 
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
-    init_tables<BM>(p, t, pxsrc, pxb, rowpix, rowb);
+    init_tables<BM, 256>(p, t, pxsrc, pxb, rowpix, rowb);
 
     int aoff[TM], boff[TN];
 #pragma unroll
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvKArgs p) {
         if (++kx == p.KW) { kx = 0; ++ky; }
         if (tap == 0) { ky = 0; kx = 0; }
     }
-    conv_epilogue<BM, BN, TM, TN>(p, t, acc, rowpix, rowb, Ws);
+    conv_epilogue<BM, BN, TM, TN, 256>(p, t, acc, rowpix, rowb, Ws);
 }
 
 template <typename K>

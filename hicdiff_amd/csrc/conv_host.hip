@@ -103,6 +103,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
 // LDS plan of one launch: tile geometry under a per-workgroup LDS budget that keeps two workgroups
 // resident per CU (160 KiB LDS), and inside the register-prefetch capacity of the kernel variant.
 static const size_t LDS_BUDGET = 78 * 1024;
+static const size_t LDS_BUDGET_8W = 150 * 1024;   // 8-wave workgroups run one per CU
 struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, variant; size_t pitch, lds; };
 
 static ConvPlan plan_conv(const ConvArgs& a) {
@@ -116,13 +117,18 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // the batch size: GroupNorm partial sums follow the tiling, and a tile's result has to be bit-identical
     // whether it is sampled alone, in a batch of 256 or on another rank.
     if (pl.fast && !wide && a.H * a.W >= 1024) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
-    pl.variant = pl.fast ? 2 + pl.cfg : pl.cfg;
+    // 256 x 128 tile with 8 waves (4 x 2): the two wave groups share every weight slab, which halves the
+    // L2 -> LDS weight traffic that bounds the K-heavy layers (Cin >= 128).
+    static const bool big = !(getenv("HICDIFF_NO_CFG3"));
+    int nthreads = 256;
+    if (pl.fast && wide && big && a.H * a.W >= 4096) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }   // measured: +5 % on hicedrn's 64x64x256 maps, a loss on small maps (one workgroup per CU)
+    pl.variant = pl.fast ? (pl.cfg == 3 ? 2 : 2 + pl.cfg) : pl.cfg;
     pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
     const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
-    long max_px = (long)((LDS_BUDGET - wbytes - 2 * pl.BM * 4) / (pl.pitch + 8));
+    long max_px = (long)(((pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET) - wbytes - 2 * pl.BM * 4) / (pl.pitch + 8));
     if (pl.fast) {
-        const long maxi = pl.ck == 32 ? (pl.cfg == 2 ? 6 : 5) : 3;
-        max_px = std::min(max_px, 256 * maxi / (pl.ck / 8));
+        const long maxi = pl.cfg == 3 ? (pl.ck == 32 ? 3 : 2) : (pl.ck == 32 ? (pl.cfg == 2 ? 6 : 5) : 3);
+        max_px = std::min(max_px, nthreads * maxi / (pl.ck / 8));
     }
     if (max_px > 512) max_px = 512;
     pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
