@@ -266,3 +266,20 @@ def test_cpu_tensors_are_refused():
     m = product_unet("uncond", 16, (1, 2))
     with pytest.raises(RuntimeError):
         m(tiles(1, 1, 16), torch.tensor([1]))
+
+
+def test_inference_cli_writes_reference_output_layout(tmp_path, precision):
+    """inference.py end to end on synthetic tiles: DDRM path and conditional path, npy layout of
+    src/Utils/metrics_diff.py:203-210."""
+    if precision != "bf16x3":
+        pytest.skip("one arithmetic mode is enough for the driver")
+    import inference
+    common = ["--resnet-blocks", "2", "--tile", "16", "--synthetic", "5", "-b", "4", "--outdir", str(tmp_path), "-s", "0.1"]
+    pred = inference.main(["-u", "1", "--sampling-steps", "10"] + common)
+    assert pred.shape == (5, 1, 16, 16) and torch.isfinite(pred).all()
+    outs = list(tmp_path.iterdir())
+    assert len(outs) == 1 and "deno_0.1_trans2_10" in outs[0].name
+    for f, shape in (("predict", (5, 1, 16, 16)), ("target", (5, 1, 16, 16)), ("noisy", (5, 1, 16, 16)), ("inds", (5,))):
+        assert np.load(outs[0] / (f + ".npy")).shape == shape
+    pred2 = inference.main(["-u", "", "--timesteps", "50", "--schedule", "linear"] + common)
+    assert pred2.shape == (5, 1, 16, 16) and torch.isfinite(pred2).all()

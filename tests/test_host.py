@@ -168,3 +168,19 @@ def test_sharded_sampling_world_size_2_gloo(tmp_path):
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
         assert b"ok" in out
+
+
+def test_cli_flags_match_the_reference():
+    """train.py / inference.py keep the reference's six flags, defaults and bool-typed -u quirk."""
+    import inference
+    import train
+    a = inference.create_parser().parse_args([])
+    assert (a.unspervised, a.batch_size, a.epoch, a.celline, a.celln, a.sigma) == (True, 64, 400, "Human", 1, 1)
+    assert inference.create_parser().parse_args(["-u", "0"]).unspervised is True       # type=bool: any non-empty string
+    assert inference.create_parser().parse_args(["-u", ""]).unspervised is False
+    t = train.create_parser().parse_args(["-b", "32", "-e", "3", "-l", "Dros", "-n", "2"])
+    assert (t.batch_size, t.epoch, t.celline, t.celln) == (32, 3, "Dros", 2)
+    with pytest.raises(NotImplementedError):
+        train.main(["--optimize"])
+    lq, hq = inference.synthetic_tiles(3, 16, 0.1, 7)
+    assert lq.shape == hq.shape == (3, 1, 16, 16) and torch.equal(hq, hq.transpose(-1, -2)) and lq.abs().max() <= 1
