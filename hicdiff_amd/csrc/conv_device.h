@@ -168,49 +168,89 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         }
         __syncthreads();
         if (nvalid > 0 && !(p.ablate & 128)) {
-#pragma unroll 4
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int lr = pass * RPP + rg;                                     // = wm*32 + row in the 32-row block
-                const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
-                const int pix = rowpix[m];
-                if (pix < 0) continue;
-                const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
-                float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+            if (p.ep == 0 && vec) {
+                // Fast path (every GroupNorm'd conv): no global load in the loop.  vmcnt retires in issue order, so a
+                // loop that mixes loads with stores makes every load wait for the previous pass's STORE round trip
+                // (measured: half of the kernel on the 64-channel full-resolution layers); here stores just stream.
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
-                const size_t o = (size_t)pix * p.Cout + n;
-                if (vec) {
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int lr = pass * RPP + rg;
+                    const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
+                    const int pix = rowpix[m];
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                    const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                    if (pix >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s1[j] += o4[j]; s2[j] += o4[j] * o4[j]; }
+                        if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                    }
+                }
+            } else if (vec) {
+                // General path: the residual / FiLM operands of pass i+1 are requested BEFORE pass i is stored, so the
+                // wait for them (vmcnt(1)) never includes the store that was issued after them.
+                float4 n_rr = make_float4(0.f, 0.f, 0.f, 0.f), n_sc = n_rr, n_sh = n_rr, n_ra = n_rr, n_rb = n_rr;
+                auto fetch = [&](int pass) {
+                    const int lr = pass * RPP + rg;
+                    const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
+                    const int pix = rowpix[m];
+                    const size_t o = (size_t)(pix < 0 ? 0 : pix) * p.Cout + n;
                     if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                         const int fo = rowb[m] * p.ep_bstride + n;
-                        const float4 sh = *reinterpret_cast<const float4*>(p.epShift + fo);
+                        n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
+                        if (p.ep & EP_FILM_SILU) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
+                    }
+                    if (p.ep & (EP_RES | EP_RES_AFFINE_SILU)) n_rr = *reinterpret_cast<const float4*>(p.res + o);
+                    if (p.ep & EP_RES_AFFINE_SILU) {
+                        const int fo = rowb[m] * p.res_bstride + n;
+                        n_ra = *reinterpret_cast<const float4*>(p.resA + fo);
+                        n_rb = *reinterpret_cast<const float4*>(p.resB + fo);
+                    }
+                };
+                fetch(0);
+#pragma unroll 2
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int lr = pass * RPP + rg;
+                    const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
+                    const int pix = rowpix[m];
+                    const float4 rr = n_rr, sc = n_sc, sh = n_sh, ra = n_ra, rb = n_rb;
+                    if (pass + 1 < NPASS) fetch(pass + 1);
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                    float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                    if (pix >= 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+                    }
+                    if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                         if (p.ep & EP_FILM_SILU) {
-                            const float4 sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                             v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
                             v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;
                         } else { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
                     }
-                    if (p.ep & EP_RES) {
-                        const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
-                        v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w;
-                    }
+                    if (p.ep & EP_RES) { v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w; }
                     if (p.ep & EP_RES_AFFINE_SILU) {
-                        const int fo = rowb[m] * p.res_bstride + n;
-                        const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
-                        const float4 ra = *reinterpret_cast<const float4*>(p.resA + fo);
-                        const float4 rb = *reinterpret_cast<const float4*>(p.resB + fo);
                         v[0] += silu_f(rr.x * ra.x + rb.x); v[1] += silu_f(rr.y * ra.y + rb.y);
                         v[2] += silu_f(rr.z * ra.z + rb.z); v[3] += silu_f(rr.w * ra.w + rb.w);
                     }
                     const f32x4 o4 = {v[0], v[1], v[2], v[3]};
-                    if (p.ablate & 512) __builtin_nontemporal_store(o4, reinterpret_cast<f32x4*>(p.out + o));
-                    else if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + o) = o4;      // one 16-byte store per lane
-                } else {
+                    if (pix >= 0 && !(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                }
+            } else {
+                // narrow outputs (Cout not a multiple of 4: the 1-channel tail of hicedrn): scalar accesses
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int lr = pass * RPP + rg;
+                    const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
+                    const int pix = rowpix[m];
+                    if (pix < 0) continue;
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                    const float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                    const size_t o = (size_t)pix * p.Cout + n;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (j >= nvalid) break;
                         float x = v[j];
+                        s1[j] += x; s2[j] += x * x;
                         if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                             const int fo = rowb[m] * p.ep_bstride + n + j;
                             x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
