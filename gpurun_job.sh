@@ -1,3 +1,6 @@
-R=$GRAFT_REPO_ROOT
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof8 -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof8.log 2>&1
+set -e
+mkdir -p gpurun_out
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+python bench.py --workload hicedrn64 --steps 3 --warmup 1 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'
+python bench.py --workload unet40 --steps 10 --warmup 3 --no-cpu-baseline 2>&1 | grep -o '"ms_per_step": [0-9.]*'

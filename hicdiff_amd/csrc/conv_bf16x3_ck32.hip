@@ -1,0 +1,36 @@
+// bf16x3 convolution, K slice of 32 channels: instantiations and dispatch (kernel: conv_bf16x3_kernel.h).
+#include "conv_bf16x3_kernel.h"
+
+#define K32(WM, WN, TM, TN, MAXI, NTAPS) conv_igemm_bf16x3_kernel<WM, WN, TM, TN, 32, MAXI, MODE, NTAPS>
+
+template <int MODE>
+static int launch_mode(ConvLaunch& L, hipStream_t st) {
+    const bool t9 = L.k.KH == 3 && L.k.KW == 3 && MODE != IN_LAYERNORM;
+    const int nt = L.cfg == 3 ? 512 : 256;
+    const int need = (L.k.npx * 4 + nt - 1) / nt;
+    if constexpr (MODE != IN_LAYERNORM) {
+        if (t9) {
+            switch (L.cfg) {
+                case 0: return need <= 3 ? launch_one(K32(2, 2, 2, 2, 3, 9), L, st) : launch_one(K32(2, 2, 2, 2, 5, 9), L, st);
+                case 1: return need <= 3 ? launch_one(K32(2, 2, 2, 1, 3, 9), L, st) : launch_one(K32(2, 2, 2, 1, 5, 9), L, st);
+                case 2: return launch_one(K32(4, 1, 2, 2, 6, 9), L, st);
+                default: return launch_one(K32(4, 2, 2, 2, 3, 9), L, st, 512);
+            }
+        }
+    }
+    switch (L.cfg) {
+        case 0: return need <= 2 ? launch_one(K32(2, 2, 2, 2, 2, 0), L, st) : launch_one(K32(2, 2, 2, 2, 8, 0), L, st);
+        case 1: return need <= 2 ? launch_one(K32(2, 2, 2, 1, 2, 0), L, st) : launch_one(K32(2, 2, 2, 1, 8, 0), L, st);
+        case 2: return launch_one(K32(4, 1, 2, 2, 4, 0), L, st);
+    }
+    hd_set_error("conv: no bf16x3 kernel variant for this tile"); return -1;
+}
+
+int launch_conv_bf16x3_ck32(ConvLaunch& L, hipStream_t st) {
+    switch (conv_kernel_mode(L)) {
+        case IN_AFFINE_SILU: return launch_mode<IN_AFFINE_SILU>(L, st);
+        case IN_AFFINE_SILU_E: return launch_mode<IN_AFFINE_SILU_E>(L, st);
+        case IN_LAYERNORM: return launch_mode<IN_LAYERNORM>(L, st);
+        default: return launch_mode<IN_NONE>(L, st);
+    }
+}

@@ -1,0 +1,410 @@
+// Split-bf16 x3 implicit-GEMM convolution on v_mfma_f32_32x32x16_bf16 -- the default arithmetic.
+//
+// Every fp32 operand is split into two bf16 values, x = hi + lo (16 significant bits), and a product
+// is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation: three MFMAs at 16x the fp32-MFMA rate.
+// Dropped terms are O(2^-17) relative: ~2e-5 error on an epsilon forward, 1e-4 on a 50-step chain
+// (plain bf16 operands give 1e-2 and fail the 1e-3 parity bound).
+//
+// LDS rows (one staged pixel of X / one output channel of W) are [CK bf16 hi | CK bf16 lo | 16 B pad];
+// the pitch 4*CK+16 bytes is an odd multiple of 16, so the 16 lanes of a ds_read_b128 group (16
+// consecutive pixels / channels) hit 16 different 16-byte bank slots.  Weights arrive pre-split
+// ([tap][Cin/CK][CoutPad][hi|lo], packed at load time) and are copied 16 bytes per lane; activations
+// are split on the fly while the loader applies its transform.
+//
+// Pipeline.  One iteration per (K slice c, filter tap), ONE barrier each.  After the barrier, in program order:
+//   1. weight slab it+1: prefetch registers -> the LDS buffer slab it-1 was read from; slab it+2 is requested;
+//   2. this tap's share of the raw fp32 values of slice c+1 is requested (registers xr);
+//   3. the MFMA cluster of iteration it.
+// Everything in 1 and 2 is asynchronous, so its latency sits behind the MFMAs instead of in front of a
+// barrier.  The loop body is STRAIGHT-LINE code (taps unrolled, last slice peeled, no data-dependent
+// branch): hipcc places exact s_waitcnt vmcnt(N) only in straight-line code -- with branches between a load
+// and its use it falls back to vmcnt(0), which serialises every load with the MFMA cluster (measured: the
+// kernel then runs at the SUM of its load, staging and MFMA times).
+// The per-slice operands of the loader transform (GroupNorm/FiLM scale and shift, LayerNorm gain) come from
+// a small double-buffered LDS table filled one slice ahead, so staging a slice touches no global memory.
+// 8-wave variant (one workgroup per CU): the activation window is double-buffered and slice c+1 is
+// transformed/split/written item by item during the taps of slice c; 4-wave variants (two workgroups per
+// CU, which overlap each other) keep one window and stage between two barriers at the slice switch.
+#pragma once
+#include "conv_device.h"
+
+#include <set>
+#include <type_traits>
+
+// Diagnostic switches (HICDIFF_ABLATE, make DIAG=1): timing experiments only.  Compiled out of the product
+// build, where their branches would break the straight-line loop body.
+#ifdef HD_DIAG
+#define ABL(bit) (p.ablate & (bit))
+#else
+#define ABL(bit) false
+#endif
+
+enum { IN_AFFINE_SILU_E = 3 };   // kernel-side mode: IN_AFFINE_SILU with the additive term inE (SR3 blocks)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned short h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hh = (__bf16)v[j];
+        const __bf16 ll = (__bf16)(v[j] - (float)hh);
+        h[j] = __builtin_bit_cast(unsigned short, hh);
+        l[j] = __builtin_bit_cast(unsigned short, ll);
+    }
+    hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+    lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+}
+
+// loader transform on 4 channels; pt: this item's entry of the slice's parameter table in LDS
+// ([vector][sample][CK] floats; vectors: scale, shift(, additive) or the LayerNorm gain), ptv: bytes per vector
+template <int MODE>
+__device__ __forceinline__ float4 xform4(float4 v, const char* pt, int ptv, float mu, float rs) {
+    if constexpr (MODE == IN_AFFINE_SILU || MODE == IN_AFFINE_SILU_E) {
+        const float4 A = *reinterpret_cast<const float4*>(pt);
+        const float4 Bv = *reinterpret_cast<const float4*>(pt + ptv);
+        v.x = silu_f(v.x * A.x + Bv.x); v.y = silu_f(v.y * A.y + Bv.y);
+        v.z = silu_f(v.z * A.z + Bv.z); v.w = silu_f(v.w * A.w + Bv.w);
+        if constexpr (MODE == IN_AFFINE_SILU_E) {
+            const float4 E = *reinterpret_cast<const float4*>(pt + 2 * ptv);
+            v.x += E.x; v.y += E.y; v.z += E.z; v.w += E.w;
+        }
+    } else if constexpr (MODE == IN_LAYERNORM) {
+        const float4 g = *reinterpret_cast<const float4*>(pt);
+        v.x = (v.x - mu) * rs * g.x; v.y = (v.y - mu) * rs * g.y;
+        v.z = (v.z - mu) * rs * g.z; v.w = (v.w - mu) * rs * g.w;
+    }
+    return v;
+}
+
+// WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread;
+// NTAPS = 9: 3x3 filter, taps unrolled; NTAPS = 0: any filter (1x1, 2x2 stride 2, ...), taps in a loop.
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+    constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = 4 * CK + 16, ROWB = 4 * CK;
+    constexpr int KS = CK / 16;                        // k16 MFMA steps per slab
+    constexpr int IPP = CK / 8;                        // 8-channel items per staged pixel
+    constexpr int NW = (BN * (CK / 4)) / NT;           // 16-byte weight pieces per thread per slab
+    constexpr int SLAB = BN * PITCH;                   // bytes of one weight slab in LDS
+    constexpr bool XDB = NT == 512 && NTAPS == 9;      // two activation windows
+    constexpr int NV = MODE == IN_NONE ? 0 : MODE == IN_LAYERNORM ? 1 : MODE == IN_AFFINE_SILU ? 2 : 3;
+    static_assert(NW >= 1 && NW <= 4 && (NT == 256 || NT == 512), "bad tile");
+    static_assert(NTAPS == 9 || NTAPS == 0, "taps are unrolled for 3x3 filters only");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int npx = p.npx;
+    const int npx4 = (npx + 3) & ~3;
+    int* pxsrc = reinterpret_cast<int*>(smem);
+    int* pxb = pxsrc + npx4;
+    int* rowpix = pxb + npx4;
+    int* rowb = rowpix + BM;
+    const int n4 = p.pt_n4;                            // 16-byte entries per table vector; entry n4 is a write sink
+    const int ptv = (n4 + 1) * 16, pt_stride = NV * ptv;
+    char* ptab = reinterpret_cast<char*>(rowb + BM);   // [2][NV][n4 + 1] float4
+    char* Ws = ptab + 2 * pt_stride;                   // [2][BN][PITCH]
+    char* Xs = Ws + 2 * SLAB;                          // [1 or 2][npx + 1][PITCH]; row npx is a write sink
+    const int xs_stride = XDB ? p.xs_stride : 0;
+
+    const TileCtx t = tile_decode<WN, BN>(p);
+    const int tid = t.tid;
+
+    // ---- parameter table: thread tid < n4 owns entry tid = (sample tid / (CK/4), channels 4 * (tid % (CK/4)))
+    const int pt_dst = (tid < n4 ? tid : n4) * 16;
+    int pt_src = 0;
+    if constexpr (NV > 0) {
+        const int e = tid < n4 ? tid : 0, bl = e / (CK / 4), q = e - bl * (CK / 4);
+        const int b = t.b0 + bl < p.B ? t.b0 + bl : p.B - 1;
+        pt_src = (MODE == IN_LAYERNORM ? 0 : b * p.in_bstride) + q * 4;
+    }
+    float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0, pr2 = pr0;
+    auto pt_load = [&](int c) {      // every lane loads (clamped entry): no branch around a memory operation
+        if constexpr (NV > 0) {
+            const int o = pt_src + c * CK;
+            pr0 = *reinterpret_cast<const float4*>((MODE == IN_LAYERNORM ? p.ln_g : p.inA) + o);
+            if constexpr (NV > 1) pr1 = *reinterpret_cast<const float4*>(p.inB + o);
+            if constexpr (NV > 2) pr2 = *reinterpret_cast<const float4*>(p.inE + o);
+        }
+    };
+    auto pt_store = [&](int c) {
+        if constexpr (NV > 0) {
+            char* d = ptab + (c & 1) * pt_stride + pt_dst;
+            *reinterpret_cast<float4*>(d) = pr0;
+            if constexpr (NV > 1) *reinterpret_cast<float4*>(d + ptv) = pr1;
+            if constexpr (NV > 2) *reinterpret_cast<float4*>(d + 2 * ptv) = pr2;
+        }
+    };
+    pt_load(0);
+    init_tables<BM, NT>(p, t, pxsrc, pxb, rowpix, rowb);
+    pt_store(0);
+
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) aoff[tm] = row_px_offset<TM>(p, t, tm) * PITCH + t.half * 16;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) boff[tn] = (t.wn * 32 * TN + tn * 32 + t.l31) * PITCH + t.half * 16;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+
+    const int ntaps = NTAPS ? NTAPS : p.KH * p.KW, nchunks = p.Cin / CK, nit = ntaps * nchunks;
+    __syncthreads();                 // tables and the parameter table of slice 0 visible
+
+    // per-thread staging items: item i = tid + NT*j = (pixel i / IPP, channels 8*(i % IPP)..+7).  NT is a
+    // multiple of IPP, so the channel offset q8 is the same for all of a thread's items and its pixels are
+    // PXSTEP apart.  Source indices are clamped so every lane issues every load; padding pixels (src < 0)
+    // are zeroed and items past the window go to the sink row when the LDS rows are written.
+    constexpr int PXSTEP = NT / IPP;
+    const int q8 = (tid % IPP) * 8, px0 = tid / IPP;
+    int it_src[MAXI], it_dst[MAXI], it_pt[MAXI];
+    bool it_pad[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        const int px = px0 + j * PXSTEP;
+        const int pxc = px < npx ? px : npx - 1;
+        const int s = pxsrc[pxc];
+        it_pad[j] = s < 0;                                       // zero padding
+        it_src[j] = s < 0 ? 0 : s;
+        it_dst[j] = (px < npx ? px : npx) * PITCH + q8 * 2;
+        it_pt[j] = ((MODE == IN_LAYERNORM ? 0 : pxb[pxc] - t.b0) * CK + q8) * 4;
+    }
+    float ln_mu[MAXI], ln_rs[MAXI];
+#pragma unroll
+    for (int j = 0; j < MAXI; ++j) {
+        ln_mu[j] = 0.f; ln_rs[j] = 1.f;
+        if constexpr (MODE == IN_LAYERNORM) {
+            const float2 st = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (size_t)it_src[j]);
+            // The two statistics are copied out of the loaded register pair.  Used in place, hipcc broadcasts
+            // rstd to both lanes of its packed multiplies straight from the pair's odd register (op_sel:[0,1]);
+            // every build that did so produced exact zeros in the low lane for the last 16 lanes of a wave on
+            // large grids (tests/test_gpu_kernels.py::test_large_grid_*), every build that did not was clean.
+            // Root cause not established (open questions).
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ln_rs[j]) : "v"(st.y));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(ln_mu[j]) : "v"(st.x));
+        }
+    }
+
+    // weight-slab prefetch registers: named scalars (an indexed array here is left in scratch by hipcc)
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+#define HD_WLOAD(k)                                                                                        \
+    if constexpr (NW > k) {                                                                                \
+        const int idx = tid + k * NT;                                                                      \
+        const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
+        w##k = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * ROWB + piece * 16);                    \
+    }
+#define HD_WSTORE(k)                                                                                       \
+    if constexpr (NW > k) {                                                                                \
+        const int idx = tid + k * NT;                                                                      \
+        const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
+        *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = w##k;                                  \
+    }
+    // slab k = (slice k / ntaps, tap k % ntaps); weights are stored [tap][slice][CoutPad][ROWB]
+    auto w_load = [&](int c, int tap) {
+        if (ABL(256)) return;
+        const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + ((size_t)(tap * nchunks + c) * p.CoutPad + t.n0) * ROWB;
+        HD_WLOAD(0) HD_WLOAD(1) HD_WLOAD(2) HD_WLOAD(3)
+    };
+    auto w_store = [&](int b) {
+        if (ABL(4)) return;
+        char* dst = Ws + b * SLAB;
+        HD_WSTORE(0) HD_WSTORE(1) HD_WSTORE(2) HD_WSTORE(3)
+    };
+
+    float4 xr[MAXI][2];
+    auto x_load = [&](int j, const float* src, int Csrc) {       // src already points at (slice, q8)
+        if (ABL(32)) return;
+        const float* g = src + (size_t)it_src[j] * Csrc;
+        xr[j][0] = *reinterpret_cast<const float4*>(g);
+        xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+    };
+    // transform + bf16 hi/lo split + LDS write of item j (raw values in xr, slice c) into window xdst
+    auto x_stage = [&](int j, int c, char* xdst) {
+        if (ABL(64)) return;
+        const char* pt = ptab + (c & 1) * pt_stride + it_pt[j];
+        const float4 v0 = xform4<MODE>(xr[j][0], pt, ptv, ln_mu[j], ln_rs[j]);
+        const float4 v1 = xform4<MODE>(xr[j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
+        uint4 hi, lo;
+        split8(v0, v1, hi, lo);
+        if (it_pad[j]) { hi = make_uint4(0, 0, 0, 0); lo = hi; }   // zero padding is applied AFTER the transform
+        char* d = xdst + it_dst[j];
+        *reinterpret_cast<uint4*>(d) = hi;
+        *reinterpret_cast<uint4*>(d + 2 * CK) = lo;
+    };
+    auto slice_src = [&](int c, const float*& src, int& Csrc) {  // channel-concatenated input: two tensors
+        const int cc = c * CK;
+        if (cc < p.C0) { src = p.in0 + cc + q8; Csrc = p.C0; } else { src = p.in1 + (cc - p.C0) + q8; Csrc = p.C1; }
+    };
+    auto mfma_cluster = [&](const char* Xc, const char* Wb, int tapoff) {
+        if (ABL(8)) return;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const char* a = Xc + aoff[tm] + tapoff + s * 32;
+                ah[tm] = *reinterpret_cast<const bf16x8*>(a);
+                al[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
+            }
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const char* b = Wb + boff[tn] + s * 32;
+                bh[tn] = *reinterpret_cast<const bf16x8*>(b);
+                bl[tn] = *reinterpret_cast<const bf16x8*>(b + 2 * CK);
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+    };
+
+    // schedule of the next slice's items over the taps of a 3x3 filter: requested during the first seven
+    // taps; with two windows, staged three taps after the request (about three MFMA clusters of cover)
+    constexpr int IPT = (MAXI + 6) / 7;
+    constexpr int XLAT = 3;
+
+    // ---- prologue: slice 0 and weight slab 0 staged, slab 1 in flight
+    {
+        const float* src; int Csrc;
+        slice_src(0, src, Csrc);
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
+        w_load(0, 0);
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) x_stage(j, 0, Xs);
+        w_store(0);
+        if (nit > 1) { if (ntaps > 1) w_load(0, 1); else w_load(1, 0); }
+    }
+
+    int buf = 0;
+    if constexpr (NTAPS == 9) {
+        // ---- slices 0 .. nchunks-2: a next slice exists, so every tap stores/requests unconditionally
+        for (int c = 0; c + 1 < nchunks; ++c) {
+            const float* nsrc; int nCsrc;
+            slice_src(c + 1, nsrc, nCsrc);
+            const char* Xc = Xs + (c & 1) * xs_stride;
+            char* Xn = Xs + ((c + 1) & 1) * xs_stride;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
+                w_store(buf ^ 1);
+                if (tap + 2 < 9) w_load(c, tap + 2); else w_load(c + 1, tap + 2 - 9);
+                if (tap == 0) pt_load(c + 1);
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j)
+                    if (j / IPT == tap) x_load(j, nsrc, nCsrc);
+                if constexpr (XDB) {
+                    if (tap == 2) pt_store(c + 1);
+#pragma unroll
+                    for (int j = 0; j < MAXI; ++j)
+                        if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
+                }
+                mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
+                buf ^= 1;
+            }
+            if constexpr (!XDB) {
+                pt_store(c + 1);
+                __syncthreads();         // single window: every wave has finished the slice
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j) x_stage(j, c + 1, Xs);
+            }
+        }
+        // ---- last slice: nothing left to request but its own weight slabs
+        {
+            const int c = nchunks - 1;
+            const char* Xc = Xs + (c & 1) * xs_stride;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                __syncthreads();
+                if (tap + 1 < 9) w_store(buf ^ 1);
+                if (tap + 2 < 9) w_load(c, tap + 2);
+                mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
+                buf ^= 1;
+            }
+        }
+    } else {
+        // ---- any filter shape: taps in a loop; tap 0 (which requests the whole next slice) and the last slice
+        // are peeled.  Slab indices past the end are clamped instead of branched around (a redundant load / a
+        // store to the idle buffer).
+        int it = 0;
+        auto w_next = [&](int k) { const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps; w_load(c, kk - c * ntaps); };
+        auto slice = [&](int c, auto has_next) {
+            constexpr bool NEXT = decltype(has_next)::value;
+            const float* nsrc = nullptr; int nCsrc = 0;
+            if constexpr (NEXT) slice_src(c + 1, nsrc, nCsrc);
+            {
+                __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
+                w_store(buf ^ 1);
+                w_next(it + 2);
+                if constexpr (NEXT) {
+                    pt_load(c + 1);
+#pragma unroll
+                    for (int j = 0; j < MAXI; ++j) x_load(j, nsrc, nCsrc);
+                }
+                mfma_cluster(Xs, Ws + buf * SLAB, 0);
+                buf ^= 1; ++it;
+            }
+            int ky = 0, kx = 1;
+            if (kx == p.KW) { kx = 0; ky = 1; }
+            for (int tap = 1; tap < ntaps; ++tap, ++it) {
+                __syncthreads();
+                w_store(buf ^ 1);
+                w_next(it + 2);
+                mfma_cluster(Xs, Ws + buf * SLAB, (ky * p.LW + kx) * PITCH);
+                buf ^= 1;
+                if (++kx == p.KW) { kx = 0; ++ky; }
+            }
+            if constexpr (NEXT) {
+                pt_store(c + 1);
+                __syncthreads();         // single window: every wave has finished the slice
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j) x_stage(j, c + 1, Xs);
+            }
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) slice(c, std::true_type{});
+        slice(nchunks - 1, std::false_type{});
+    }
+    (void)w1; (void)w2; (void)w3; (void)pr1; (void)pr2;
+#undef HD_WLOAD
+#undef HD_WSTORE
+    conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(ptab));
+}
+
+template <typename K>
+static int launch_one(K kernel, ConvLaunch& L, hipStream_t st, int nthreads = 256) {
+    static std::set<const void*> raised;   // every instantiation has the same pointer TYPE: key by address
+    if (!raised.count(reinterpret_cast<const void*>(kernel))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            hd_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
+        }
+        raised.insert(reinterpret_cast<const void*>(kernel));
+    }
+    const ConvKArgs& k = L.k;
+    const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
+    dim3 grid((unsigned)(mtiles * k.ntiles_n));
+    conv_prof_begin(L, st);
+    hipLaunchKernelGGL(kernel, grid, dim3(nthreads), L.lds, st, L.k);
+    conv_prof_end(st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hd_set_error(std::string("conv launch: ") + hipGetErrorString(e)); return -3; }
+    return 0;
+}
+
+// kernel-side loader mode of a launch
+static inline int conv_kernel_mode(const ConvLaunch& L) {
+    if (L.k.in_mode == IN_AFFINE_SILU) return L.k.inE ? IN_AFFINE_SILU_E : IN_AFFINE_SILU;
+    return L.k.in_mode;
+}
+
+// Largest window (in staged 8-channel items per thread) a launch may use; conv_host.hip plans the tile inside
+// it and the dispatch below picks the smallest instantiated variant that holds the window.
+int conv_bf16x3_max_items(int cfg, int ck, bool taps9, bool layernorm);

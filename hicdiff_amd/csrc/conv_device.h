@@ -14,6 +14,8 @@ struct ConvKArgs {
     const float* w; const unsigned short* wsplit; const float* bias;
     int Cout, CoutPad;
     int TB, TH, TW, LH, LW, npx, tiles_x, tiles_y, ntiles_n;
+    int xs_stride;               // bf16x3 kernel: bytes between its two activation windows in LDS (0: single window)
+    int pt_n4;                   // bf16x3 kernel: 16-byte entries per vector of the loader-parameter table (TB * CK / 4; LayerNorm: CK / 4)
     int in_mode; const float* inA; const float* inB; const float* inE; int in_bstride;
     const float* ln_stats; const float* ln_g;
     int ep; const float* epScale; const float* epShift; int ep_bstride;
@@ -294,5 +296,6 @@ struct ConvLaunch {
 };
 int launch_conv_f32(ConvLaunch& L, hipStream_t st);
 int launch_conv_bf16x3(ConvLaunch& L, hipStream_t st);
+int conv_bf16x3_max_items(int cfg, int ck, bool taps9, bool layernorm);
 void conv_prof_begin(const ConvLaunch& L, hipStream_t st);
 void conv_prof_end(hipStream_t st);

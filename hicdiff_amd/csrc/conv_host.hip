@@ -85,7 +85,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
     for (int tw = 1; tw <= W && tw <= BM; ++tw) {
         for (int th = 1; th <= H && th * tw <= BM; ++th) {
             int tb = 1;
-            if (th == H && tw == W) { tb = BM / (H * W); if (tb > B) tb = B; if (tb < 1) tb = 1; }
+            if (th == H && tw == W) { tb = BM / (H * W); if (tb > B) tb = B; if (tb > 32) tb = 32; if (tb < 1) tb = 1; }   // 32: loader-parameter table of the bf16x3 kernel
             long lh = (long)(th - 1) * stride + KH, lw = (long)(tw - 1) * stride + KW;
             long npx = tb * lh * lw;
             if (npx > max_px) continue;
@@ -104,7 +104,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
 // resident per CU (160 KiB LDS), and inside the register-prefetch capacity of the kernel variant.
 static const size_t LDS_BUDGET = 78 * 1024;
 static const size_t LDS_BUDGET_8W = 150 * 1024;   // 8-wave workgroups run one per CU
-struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, variant; size_t pitch, lds; };
+struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, variant, xs_stride, pt_n4; size_t pitch, lds; };
 
 static ConvPlan plan_conv(const ConvArgs& a) {
     ConvPlan pl{};
@@ -116,26 +116,36 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // 256 x 64 tile (waves 4 x 1) for 64-channel outputs on large feature maps.  The choice must not depend on
     // the batch size: GroupNorm partial sums follow the tiling, and a tile's result has to be bit-identical
     // whether it is sampled alone, in a batch of 256 or on another rank.
-    if (pl.fast && !wide && a.H * a.W >= 1024) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
-    // 256 x 128 tile with 8 waves (4 x 2): the two wave groups share every weight slab, which halves the
-    // L2 -> LDS weight traffic that bounds the K-heavy layers (Cin >= 128).
+    const int ntaps = a.cw.KH * a.cw.KW;
+    const bool ln = a.in_mode == IN_LAYERNORM;
+    const bool taps9 = a.cw.KH == 3 && a.cw.KW == 3 && !ln;      // kernels with unrolled taps
+    if (pl.fast && !wide && a.H * a.W >= 1024 && (taps9 || ntaps == 1)) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
+    // 256 x 128 tile with 8 waves (4 x 2), one workgroup per CU: the two wave groups share every weight slab
+    // (half the L2 -> LDS weight traffic of the K-heavy layers) and the activation window is double-buffered.
     static const bool big = !(getenv("HICDIFF_NO_CFG3"));
     int nthreads = 256;
-    if (pl.fast && wide && big && a.H * a.W >= 4096) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }   // measured: +5 % on hicedrn's 64x64x256 maps, a loss on small maps (one workgroup per CU)
+    if (pl.fast && wide && big && taps9 && a.H * a.W >= 4096) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
     pl.variant = pl.fast ? (pl.cfg == 3 ? 2 : 2 + pl.cfg) : pl.cfg;
     pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
     const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
-    long max_px = (long)(((pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET) - wbytes - 2 * pl.BM * 4) / (pl.pitch + 8));
-    if (pl.fast) {
-        const long maxi = pl.cfg == 3 ? (pl.ck == 32 ? 3 : 2) : (pl.ck == 32 ? (pl.cfg == 2 ? 6 : 5) : 3);
-        max_px = std::min(max_px, nthreads * maxi / (pl.ck / 8));
-    }
+    const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
+    // bf16x3: one sink row per window; the 8-wave variant double-buffers the window; loader-parameter table
+    // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest)
+    const int nxb = pl.fast && pl.cfg == 3 ? 2 : 1;
+    const int nv = !pl.fast || a.in_mode == IN_NONE ? 0 : ln ? 1 : a.inE ? 3 : 2;
+    const size_t pt_reserve = (size_t)2 * nv * ((ln ? 1 : 32) * pl.ck / 4 + 1) * 16;
+    long max_px = (long)((budget - wbytes - pt_reserve - 2 * pl.BM * 4 - (pl.fast ? nxb * pl.pitch : 0)) / (nxb * pl.pitch + 8));
+    if (pl.fast) max_px = std::min<long>(max_px, (long)nthreads * conv_bf16x3_max_items(pl.cfg, pl.ck, taps9, ln) / (pl.ck / 8));
     if (max_px > 512) max_px = 512;
     pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
     const int LH = (pl.g.TH - 1) * a.stride + a.cw.KH, LW = (pl.g.TW - 1) * a.stride + a.cw.KW;
     const int npx = pl.g.TB * LH * LW, npx4 = (npx + 3) & ~3;
     const size_t stage = (size_t)(pl.BM / 2) * (pl.BN + 4) * 4;  // epilogue staging (TM = 2 rounds) overlays the operand buffers
-    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(wbytes + (size_t)npx * pl.pitch, stage);
+    const size_t xwin = pl.fast ? (size_t)(npx + 1) * pl.pitch : (size_t)npx * pl.pitch;
+    pl.xs_stride = nxb == 2 ? (int)xwin : 0;
+    pl.pt_n4 = nv ? (ln ? 1 : pl.g.TB) * pl.ck / 4 : 0;
+    const size_t ptbytes = (size_t)2 * nv * (pl.pt_n4 + 1) * 16;
+    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(ptbytes + wbytes + nxb * xwin, stage);
     return pl;
 }
 
@@ -175,6 +185,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
     L.lds = pl.lds; L.variant = pl.variant; L.ck = pl.ck; L.cfg = pl.cfg;
+    k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
+    if (pl.fast && pl.pt_n4 > 256) { hd_set_error("conv: loader-parameter table needs more than 256 entries per vector"); return -1; }
     if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }
     return pl.fast ? launch_conv_bf16x3(L, st) : launch_conv_f32(L, st);
 }
