@@ -108,6 +108,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
 
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
+    if (p.stagger) {
+        const int mode = p.stagger >> 16, n = p.stagger & 0xffff, b = blockIdx.x;
+        const bool hit = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : (b >> 3) & 1);
+        if (hit) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ---- parameter table: thread tid < n4 owns entry tid = (sample tid / (CK/4), channels 4 * (tid % (CK/4)))
     const int pt_dst = (tid < n4 ? tid : n4) * 16;
@@ -189,31 +194,46 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
         }
     }
 
-    // weight-slab prefetch registers: named scalars (an indexed array here is left in scratch by hipcc)
-    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-#define HD_WLOAD(k)                                                                                        \
+    // weight-slab prefetch registers: named scalars (an indexed array here is left in scratch by hipcc).
+    // 3x3 kernels keep THREE sets in flight (slab s travels in set s % 3; nine taps per slice make that a
+    // compile-time index): a slab is requested three iterations before it is written to LDS.  The distance
+    // matters twice over: it covers the weights' own L2 latency, and -- vmcnt retiring in issue order -- the wait
+    // for a slab also waits for every activation load issued before that slab was requested, so it is what gives
+    // the (HBM-latency) activation loads their three iterations of runway.
+    constexpr int WD = NTAPS == 9 && !(NW == 4 && MAXI > 3) ? 3 : 1;   // (the largest-window 128 x 128 variant would lose its second workgroup per CU to the extra registers)
+    uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0, v0 = w0, v1 = w0, v2 = w0, v3 = w0, u0 = w0, u1 = w0, u2 = w0, u3 = w0;
+#define HD_WLOAD(S, k)                                                                                     \
     if constexpr (NW > k) {                                                                                \
         const int idx = tid + k * NT;                                                                      \
         const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
-        w##k = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * ROWB + piece * 16);                    \
+        S##k = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * ROWB + piece * 16);                    \
     }
-#define HD_WSTORE(k)                                                                                       \
+#define HD_WSTORE(S, k)                                                                                    \
     if constexpr (NW > k) {                                                                                \
         const int idx = tid + k * NT;                                                                      \
         const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
-        *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = w##k;                                  \
+        *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = S##k;                                  \
     }
     // slab k = (slice k / ntaps, tap k % ntaps); weights are stored [tap][slice][CoutPad][ROWB]
-    auto w_load = [&](int c, int tap) {
+    auto w_load = [&](auto set, int c, int tap) {
         if (ABL(256)) return;
+        constexpr int S = decltype(set)::value;
         const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + ((size_t)(tap * nchunks + c) * p.CoutPad + t.n0) * ROWB;
-        HD_WLOAD(0) HD_WLOAD(1) HD_WLOAD(2) HD_WLOAD(3)
+        if constexpr (S == 0) { HD_WLOAD(w, 0) HD_WLOAD(w, 1) HD_WLOAD(w, 2) HD_WLOAD(w, 3) }
+        else if constexpr (S == 1) { HD_WLOAD(v, 0) HD_WLOAD(v, 1) HD_WLOAD(v, 2) HD_WLOAD(v, 3) }
+        else { HD_WLOAD(u, 0) HD_WLOAD(u, 1) HD_WLOAD(u, 2) HD_WLOAD(u, 3) }
     };
-    auto w_store = [&](int b) {
+    auto w_store = [&](auto set, int b) {
         if (ABL(4)) return;
+        constexpr int S = decltype(set)::value;
         char* dst = Ws + b * SLAB;
-        HD_WSTORE(0) HD_WSTORE(1) HD_WSTORE(2) HD_WSTORE(3)
+        if constexpr (S == 0) { HD_WSTORE(w, 0) HD_WSTORE(w, 1) HD_WSTORE(w, 2) HD_WSTORE(w, 3) }
+        else if constexpr (S == 1) { HD_WSTORE(v, 0) HD_WSTORE(v, 1) HD_WSTORE(v, 2) HD_WSTORE(v, 3) }
+        else { HD_WSTORE(u, 0) HD_WSTORE(u, 1) HD_WSTORE(u, 2) HD_WSTORE(u, 3) }
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
 
     float4 xr[MAXI][2];
     auto x_load = [&](int j, const float* src, int Csrc) {       // src already points at (slice, q8)
@@ -278,39 +298,59 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
         slice_src(0, src, Csrc);
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
-        w_load(0, 0);
+        w_load(S0{}, 0, 0);
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_stage(j, 0, Xs);
-        w_store(0);
-        if (nit > 1) { if (ntaps > 1) w_load(0, 1); else w_load(1, 0); }
+        w_store(S0{}, 0);
+        if constexpr (WD == 3) {          // slabs 1, 2, 3 (a 3x3 filter has nine per slice)
+            w_load(S1{}, 0, 1); w_load(S2{}, 0, 2); w_load(S0{}, 0, 3);
+        } else if constexpr (NTAPS == 9) {
+            w_load(S0{}, 0, 1);
+        } else if (nit > 1) {
+            if (ntaps > 1) w_load(S0{}, 0, 1); else w_load(S0{}, 1, 0);
+        }
     }
 
     int buf = 0;
     if constexpr (NTAPS == 9) {
-        // ---- slices 0 .. nchunks-2: a next slice exists, so every tap stores/requests unconditionally
+        // One tap of the main loop, tap index known at compile time.  NEXT: a next slice exists (slices
+        // 0 .. nchunks-2), so the tap stores/requests unconditionally; the last slice only drains its own slabs.
+        auto tap_body = [&](auto tapc, auto has_next, int c, const char* Xc, char* Xn, const float* nsrc, int nCsrc) {
+            constexpr int tap = decltype(tapc)::value;
+            constexpr bool NEXT = decltype(has_next)::value;
+            using SN = std::integral_constant<int, (tap + 1) % WD>;
+            __syncthreads();             // slab `it` and the window of slice c are visible; nobody still reads slab it-1
+            // slab it+1 (set (tap+1) % WD) -> LDS, then slab it+1+WD is requested into the set just freed
+            if constexpr (NEXT || tap + 1 < 9) w_store(SN{}, buf ^ 1);
+            if constexpr (tap + 1 + WD < 9) w_load(SN{}, c, tap + 1 + WD);
+            else if constexpr (NEXT) w_load(SN{}, c + 1, tap + 1 + WD - 9);
+            if constexpr (NEXT) {
+                if constexpr (tap == 0) pt_load(c + 1);
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j)
+                    if (j / IPT == tap) x_load(j, nsrc, nCsrc);
+                if constexpr (XDB) {
+                    if constexpr (tap == 2) pt_store(c + 1);
+#pragma unroll
+                    for (int j = 0; j < MAXI; ++j)
+                        if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
+                }
+            }
+            mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
+            buf ^= 1;
+        };
+#define HD_NINE_TAPS(NEXT_T, ...)                                                                          \
+        tap_body(std::integral_constant<int, 0>{}, NEXT_T{}, __VA_ARGS__); tap_body(std::integral_constant<int, 1>{}, NEXT_T{}, __VA_ARGS__); \
+        tap_body(std::integral_constant<int, 2>{}, NEXT_T{}, __VA_ARGS__); tap_body(std::integral_constant<int, 3>{}, NEXT_T{}, __VA_ARGS__); \
+        tap_body(std::integral_constant<int, 4>{}, NEXT_T{}, __VA_ARGS__); tap_body(std::integral_constant<int, 5>{}, NEXT_T{}, __VA_ARGS__); \
+        tap_body(std::integral_constant<int, 6>{}, NEXT_T{}, __VA_ARGS__); tap_body(std::integral_constant<int, 7>{}, NEXT_T{}, __VA_ARGS__); \
+        tap_body(std::integral_constant<int, 8>{}, NEXT_T{}, __VA_ARGS__);
         for (int c = 0; c + 1 < nchunks; ++c) {
             const float* nsrc; int nCsrc;
             slice_src(c + 1, nsrc, nCsrc);
             const char* Xc = Xs + (c & 1) * xs_stride;
             char* Xn = Xs + ((c + 1) & 1) * xs_stride;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
-                w_store(buf ^ 1);
-                if (tap + 2 < 9) w_load(c, tap + 2); else w_load(c + 1, tap + 2 - 9);
-                if (tap == 0) pt_load(c + 1);
-#pragma unroll
-                for (int j = 0; j < MAXI; ++j)
-                    if (j / IPT == tap) x_load(j, nsrc, nCsrc);
-                if constexpr (XDB) {
-                    if (tap == 2) pt_store(c + 1);
-#pragma unroll
-                    for (int j = 0; j < MAXI; ++j)
-                        if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
-                }
-                mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
-                buf ^= 1;
-            }
+            HD_NINE_TAPS(std::true_type, c, Xc, Xn, nsrc, nCsrc)
             if constexpr (!XDB) {
                 pt_store(c + 1);
                 __syncthreads();         // single window: every wave has finished the slice
@@ -318,32 +358,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
                 for (int j = 0; j < MAXI; ++j) x_stage(j, c + 1, Xs);
             }
         }
-        // ---- last slice: nothing left to request but its own weight slabs
         {
             const int c = nchunks - 1;
             const char* Xc = Xs + (c & 1) * xs_stride;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                __syncthreads();
-                if (tap + 1 < 9) w_store(buf ^ 1);
-                if (tap + 2 < 9) w_load(c, tap + 2);
-                mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
-                buf ^= 1;
-            }
+            HD_NINE_TAPS(std::false_type, c, Xc, nullptr, nullptr, 0)
         }
+#undef HD_NINE_TAPS
     } else {
         // ---- any filter shape: taps in a loop; tap 0 (which requests the whole next slice) and the last slice
         // are peeled.  Slab indices past the end are clamped instead of branched around (a redundant load / a
         // store to the idle buffer).
         int it = 0;
-        auto w_next = [&](int k) { const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps; w_load(c, kk - c * ntaps); };
+        auto w_next = [&](int k) { const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps; w_load(S0{}, c, kk - c * ntaps); };
         auto slice = [&](int c, auto has_next) {
             constexpr bool NEXT = decltype(has_next)::value;
             const float* nsrc = nullptr; int nCsrc = 0;
             if constexpr (NEXT) slice_src(c + 1, nsrc, nCsrc);
             {
                 __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
-                w_store(buf ^ 1);
+                w_store(S0{}, buf ^ 1);
                 w_next(it + 2);
                 if constexpr (NEXT) {
                     pt_load(c + 1);
@@ -357,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
             if (kx == p.KW) { kx = 0; ky = 1; }
             for (int tap = 1; tap < ntaps; ++tap, ++it) {
                 __syncthreads();
-                w_store(buf ^ 1);
+                w_store(S0{}, buf ^ 1);
                 w_next(it + 2);
                 mfma_cluster(Xs, Ws + buf * SLAB, (ky * p.LW + kx) * PITCH);
                 buf ^= 1;
@@ -373,7 +406,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
         for (int c = 0; c + 1 < nchunks; ++c) slice(c, std::true_type{});
         slice(nchunks - 1, std::false_type{});
     }
-    (void)w1; (void)w2; (void)w3; (void)pr1; (void)pr2;
+    (void)w1; (void)w2; (void)w3; (void)v0; (void)v1; (void)v2; (void)v3; (void)u0; (void)u1; (void)u2; (void)u3; (void)pr1; (void)pr2;
 #undef HD_WLOAD
 #undef HD_WSTORE
     conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(ptab));

@@ -22,6 +22,7 @@ struct ConvKArgs {
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     float* out; float* gn_part; int gn_slots;
     unsigned long long* stamp;   // diagnostic build only (HD_STAMP): per-phase cycle sums, 8 counters
+    int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };
 

@@ -130,10 +130,11 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
     const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
     // bf16x3: one sink row per window; the 8-wave variant double-buffers the window; loader-parameter table
-    // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest)
+    // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest possible)
     const int nxb = pl.fast && pl.cfg == 3 ? 2 : 1;
     const int nv = !pl.fast || a.in_mode == IN_NONE ? 0 : ln ? 1 : a.inE ? 3 : 2;
-    const size_t pt_reserve = (size_t)2 * nv * ((ln ? 1 : 32) * pl.ck / 4 + 1) * 16;
+    const int tb_max = std::max(1, std::min(32, pl.BM / std::max(1, a.H * a.W)));   // TB > 1 only when whole images fit in the tile
+    const size_t pt_reserve = (size_t)2 * nv * ((ln ? 1 : tb_max) * pl.ck / 4 + 1) * 16;
     long max_px = (long)((budget - wbytes - pt_reserve - 2 * pl.BM * 4 - (pl.fast ? nxb * pl.pitch : 0)) / (nxb * pl.pitch + 8));
     if (pl.fast) max_px = std::min<long>(max_px, (long)nthreads * conv_bf16x3_max_items(pl.cfg, pl.ck, taps9, ln) / (pl.ck / 8));
     if (max_px > 512) max_px = 512;
@@ -169,6 +170,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.out = a.out;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
+    static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;
+    k.stagger = stagger;
     k.stamp = g_stamp;
     const ConvPlan pl = plan_conv(a);
     if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
