@@ -37,6 +37,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-le
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA; the split-bf16 x3 conv issues 3 MFMA flops per algorithmic flop
 PEAK_HBM_GBS = 8000.0
 T_CHAIN = 1000
+# HBM bytes per launch of each kernel from the FETCH_SIZE / WRITE_SIZE passes of this round (separate rocprofv3
+# --pmc runs of this script; profiles/README.md): a recorded measurement, reported as roofline.traffic with its source.
+TRAFFIC_FILE = {"unet64": os.path.join(ROOT, "profiles", "r01_c_unet64_b256_hbm_traffic.json")}
+
+
+def recorded_traffic(workload, kernel, batch, default_batch):
+    path = TRAFFIC_FILE.get(workload)
+    if batch != default_batch or not path or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        rec = json.load(f)
+    for name, row in rec["kernels"].items():
+        if kernel in name:
+            return row["fetch_bytes_per_launch"] + row["write_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
 
 
 def build_model(w, device):
@@ -160,8 +175,9 @@ def main():
         diff._step_inplace(img, t, cond)
         t -= 1
     barrier()
-    rows = (L.HdProfileRow * L.HD_PROFILE_ROWS)()
-    lib.hd_profile_read(rows)
+    rows_buf = (L.HdProfileRow * L.HD_PROFILE_MAX_ROWS)()
+    n_rows = lib.hd_profile_read(rows_buf, L.HD_PROFILE_MAX_ROWS)
+    rows = [rows_buf[i] for i in range(max(n_rows, 0))]
     lib.hd_profile_enable(0)
 
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -186,9 +202,11 @@ def main():
         ach = dom.flops / (dom.total_ms * 1e-3) / 1e12 if dom.total_ms > 0 else 0.0
         split = b"bf16x3" in dom.kernel
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        traffic, traffic_src = recorded_traffic(args.workload, dom.kernel.decode(), B, WORK[args.workload]["B"])
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": None,
+            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom.bytes / max(dom.launches, 1)),
             "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 MFMA 2500 / 3 MFMAs per product (split-bf16 x3)"
                           if split else "exact-fp32 MFMA peak"),
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),

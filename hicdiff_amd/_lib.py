@@ -16,7 +16,7 @@ HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
 HD_PRECISION_F32, HD_PRECISION_BF16X3 = 0, 1
-HD_PROFILE_ROWS = 5
+HD_PROFILE_MAX_ROWS = 96
 
 
 class HdArchDesc(C.Structure):
@@ -67,7 +67,7 @@ SYMBOLS = {
     "hd_q_sample": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "hd_loss_per_sample": (C.c_int, [_P, _P, _P, C.c_int, _P, C.c_int, C.c_int, _P]),
     "hd_profile_enable": (C.c_int, [C.c_int]),
-    "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow)]),
+    "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow), C.c_int]),
     "hd_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_set_graphs": (C.c_int, [_P, C.c_int]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),

@@ -1,7 +1,10 @@
 // bf16x3 convolution, K slice of 32 channels: instantiations and dispatch (kernel: conv_bf16x3_kernel.h).
 #include "conv_bf16x3_kernel.h"
 
-#define K32(WM, WN, TM, TN, MAXI, NTAPS) conv_igemm_bf16x3_kernel<WM, WN, TM, TN, 32, MAXI, MODE, NTAPS>
+// kernel pointer + its profiler name, spelled as rocprofv3 prints the instantiation (built only while profiling)
+#define K32(WM, WN, TM, TN, MAXI, NTAPS)                                                                   \
+    conv_igemm_bf16x3_kernel<WM, WN, TM, TN, 32, MAXI, MODE, NTAPS>,                                              \
+        conv_prof_name("conv_igemm_bf16x3_kernel<" #WM ", " #WN ", " #TM ", " #TN ", 32, " #MAXI ", ", MODE, ", " #NTAPS ">")
 
 template <int MODE>
 static int launch_mode(ConvLaunch& L, hipStream_t st) {

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
 }
 
 template <typename K>
-static int launch_one(K kernel, ConvLaunch& L, hipStream_t st, int nthreads = 256) {
+static int launch_one(K kernel, const char* name, ConvLaunch& L, hipStream_t st, int nthreads = 256) {
     static std::set<const void*> raised;   // every instantiation has the same pointer TYPE: key by address
     if (!raised.count(reinterpret_cast<const void*>(kernel))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -424,7 +424,7 @@ static int launch_one(K kernel, ConvLaunch& L, hipStream_t st, int nthreads = 25
     const ConvKArgs& k = L.k;
     const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
     dim3 grid((unsigned)(mtiles * k.ntiles_n));
-    conv_prof_begin(L, st);
+    conv_prof_begin(L, name, st);
     hipLaunchKernelGGL(kernel, grid, dim3(nthreads), L.lds, st, L.k);
     conv_prof_end(st);
     hipError_t e = hipGetLastError();
@@ -441,3 +441,4 @@ static inline int conv_kernel_mode(const ConvLaunch& L) {
 // Largest window (in staged 8-channel items per thread) a launch may use; conv_host.hip plans the tile inside
 // it and the dispatch below picks the smallest instantiated variant that holds the window.
 int conv_bf16x3_max_items(int cfg, int ck, bool taps9, bool layernorm);
+

@@ -21,7 +21,6 @@ struct ConvKArgs {
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     float* out; float* gn_part; int gn_slots;
-    unsigned long long* stamp;   // diagnostic build only (HD_STAMP): per-phase cycle sums, 8 counters
     int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };
@@ -291,12 +290,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
 struct ConvLaunch {
     ConvKArgs k;
     size_t lds;
-    int variant;     // profiler row
     int ck;          // K slice
     int cfg;         // 0: 128 x 128 tile (waves 2 x 2), 1: 128 x 64 (2 x 2), 2: 256 x 64 (4 x 1), 3: 256 x 128 (8 waves, 4 x 2)
 };
 int launch_conv_f32(ConvLaunch& L, hipStream_t st);
 int launch_conv_bf16x3(ConvLaunch& L, hipStream_t st);
 int conv_bf16x3_max_items(int cfg, int ck, bool taps9, bool layernorm);
-void conv_prof_begin(const ConvLaunch& L, hipStream_t st);
+void conv_prof_begin(const ConvLaunch& L, const char* name, hipStream_t st);   // name: the instantiation as rocprofv3 prints it (string literal)
 void conv_prof_end(hipStream_t st);
+const char* conv_prof_name(const char* head, int mode, const char* tail);   // interned "head<mode>tail"; nullptr while the profiler is off

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(ConvKArgs p) {
 }
 
 template <typename K>
-static int launch_one(K kernel, ConvLaunch& L, hipStream_t st) {
+static int launch_one(K kernel, const char* name, ConvLaunch& L, hipStream_t st) {
     static std::set<const void*> raised;   // every instantiation has the same pointer TYPE: key by address
     if (!raised.count(reinterpret_cast<const void*>(kernel))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -117,7 +117,7 @@ static int launch_one(K kernel, ConvLaunch& L, hipStream_t st) {
     const ConvKArgs& k = L.k;
     const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
     dim3 grid((unsigned)(mtiles * k.ntiles_n));
-    conv_prof_begin(L, st);
+    conv_prof_begin(L, name, st);
     hipLaunchKernelGGL(kernel, grid, dim3(256), L.lds, st, L.k);
     conv_prof_end(st);
     hipError_t e = hipGetLastError();
@@ -126,6 +126,6 @@ static int launch_one(K kernel, ConvLaunch& L, hipStream_t st) {
 }
 
 int launch_conv_f32(ConvLaunch& L, hipStream_t st) {
-    if (L.cfg == 0) return launch_one(conv_igemm_f32_kernel<2, 2, 16>, L, st);
-    return launch_one(conv_igemm_f32_kernel<2, 1, 16>, L, st);
+    if (L.cfg == 0) return launch_one(conv_igemm_f32_kernel<2, 2, 16>, conv_prof_name("conv_igemm_f32_kernel<2, 2, 16>", -1, ""), L, st);
+    return launch_one(conv_igemm_f32_kernel<2, 1, 16>, conv_prof_name("conv_igemm_f32_kernel<2, 1, 16>", -1, ""), L, st);
 }

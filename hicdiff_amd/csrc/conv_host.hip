@@ -22,11 +22,12 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <tuple>
 #include <vector>
 
 // ---- per-launch timing with HIP events on the launch stream (hd_profile_* in hicdiff_hip.h) ------
-struct ProfRec { int variant; double flops, bytes; hipEvent_t e0, e1; };
+struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static ProfRec g_cur;
@@ -36,26 +37,33 @@ void hd_prof_enable(bool on) {
     g_prof.clear();
     g_prof_on = on;
 }
-void hd_prof_collect(double* ms, double* flops, double* bytes, long long* launches) {
-    for (int v = 0; v < HD_PROF_VARIANTS; ++v) { ms[v] = flops[v] = bytes[v] = 0.0; launches[v] = 0; }
+// One row per kernel instantiation (the name rocprofv3 prints for it), in order of first launch.
+int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes, long long* launches, int max_rows) {
+    int n = 0;
     for (auto& r : g_prof) {
         float t = 0.f;
-        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) {
-            ms[r.variant] += t; flops[r.variant] += r.flops; bytes[r.variant] += r.bytes; launches[r.variant] += 1;
+        if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        int v = 0;
+        while (v < n && names[v] != r.name) ++v;      // names are string literals: pointer identity
+        if (v == n) {
+            if (n == max_rows) continue;
+            names[n] = r.name; ms[n] = flops[n] = bytes[n] = 0.0; launches[n] = 0; ++n;
         }
+        ms[v] += t; flops[v] += r.flops; bytes[v] += r.bytes; launches[v] += 1;
     }
+    return n;
 }
-const char* hd_prof_variant_name(int v) {
-    static const char* names[HD_PROF_VARIANTS] = {
-        "conv_igemm_f32_kernel<2,2,16>", "conv_igemm_f32_kernel<2,1,16>",
-        "conv_igemm_bf16x3_kernel<128x128>", "conv_igemm_bf16x3_kernel<128x64>", "conv_igemm_bf16x3_kernel<256x64>"};
-    return names[v];
+const char* conv_prof_name(const char* head, int mode, const char* tail) {
+    if (!g_prof_on) return nullptr;
+    static std::map<std::string, std::string> names;      // node addresses are stable: pointer identity = same name
+    const std::string key = std::string(head) + (mode >= 0 ? std::to_string(mode) : std::string()) + tail;
+    return names.emplace(key, key).first->second.c_str();
 }
-void conv_prof_begin(const ConvLaunch& L, hipStream_t st) {
+void conv_prof_begin(const ConvLaunch& L, const char* name, hipStream_t st) {
     if (!g_prof_on) return;
     const ConvKArgs& k = L.k;
     g_cur = ProfRec{};
-    g_cur.variant = L.variant;
+    g_cur.name = name;
     g_cur.flops = 2.0 * k.B * k.H * k.W * (double)k.Cout * k.Cin * k.KH * k.KW;
     g_cur.bytes = 4.0 * ((double)k.B * k.IH * k.IW * k.Cin + (double)k.B * k.H * k.W * k.Cout + (double)k.KH * k.KW * k.Cin * k.Cout);
     (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
@@ -66,9 +74,6 @@ void conv_prof_end(hipStream_t st) {
     (void)hipEventRecord(g_cur.e1, st);
     g_prof.push_back(g_cur);
 }
-
-// diagnostic build: device buffer of 8 phase counters (hd_debug_stamp_* in engine.hip)
-unsigned long long* g_stamp = nullptr;
 
 // ---- tile planning ---------------------------------------------------------------------------------
 struct TileGeom { int TB, TH, TW; };
@@ -104,7 +109,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
 // resident per CU (160 KiB LDS), and inside the register-prefetch capacity of the kernel variant.
 static const size_t LDS_BUDGET = 78 * 1024;
 static const size_t LDS_BUDGET_8W = 150 * 1024;   // 8-wave workgroups run one per CU
-struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, variant, xs_stride, pt_n4; size_t pitch, lds; };
+struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, xs_stride, pt_n4; size_t pitch, lds; };
 
 static ConvPlan plan_conv(const ConvArgs& a) {
     ConvPlan pl{};
@@ -125,7 +130,6 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     static const bool big = !(getenv("HICDIFF_NO_CFG3"));
     int nthreads = 256;
     if (pl.fast && wide && big && taps9 && a.H * a.W >= 4096) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
-    pl.variant = pl.fast ? (pl.cfg == 3 ? 2 : 2 + pl.cfg) : pl.cfg;
     pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
     const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
     const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
@@ -172,7 +176,6 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ablate = ablate;
     static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;
     k.stagger = stagger;
-    k.stamp = g_stamp;
     const ConvPlan pl = plan_conv(a);
     if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
         hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");
@@ -187,7 +190,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.gn_part = nullptr; k.gn_slots = 0;
     if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
-    L.lds = pl.lds; L.variant = pl.variant; L.ck = pl.ck; L.cfg = pl.cfg;
+    L.lds = pl.lds; L.ck = pl.ck; L.cfg = pl.cfg;
     k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
     if (pl.fast && pl.pt_n4 > 256) { hd_set_error("conv: loader-parameter table needs more than 256 entries per vector"); return -1; }
     if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }

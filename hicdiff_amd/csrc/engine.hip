@@ -835,31 +835,16 @@ int hd_set_precision(hd_ctx* c, int mode) {
     return HD_OK;
 }
 
-int hd_profile_read(hd_profile_row rows[HD_PROFILE_ROWS]) {
-    if (!rows) return HD_EINVAL;
-    double ms[HD_PROF_VARIANTS], fl[HD_PROF_VARIANTS], by[HD_PROF_VARIANTS]; long long n[HD_PROF_VARIANTS];
-    hd_prof_collect(ms, fl, by, n);
-    for (int v = 0; v < HD_PROF_VARIANTS; ++v) { rows[v].kernel = hd_prof_variant_name(v); rows[v].launches = n[v]; rows[v].total_ms = ms[v]; rows[v].flops = fl[v]; rows[v].bytes = by[v]; }
-    return HD_OK;
+int hd_profile_read(hd_profile_row* rows, int max_rows) {
+    if (!rows || max_rows <= 0) return HD_EINVAL;
+    if (max_rows > HD_PROFILE_MAX_ROWS) max_rows = HD_PROFILE_MAX_ROWS;
+    const char* names[HD_PROFILE_MAX_ROWS]; double ms[HD_PROFILE_MAX_ROWS], fl[HD_PROFILE_MAX_ROWS], by[HD_PROFILE_MAX_ROWS]; long long n[HD_PROFILE_MAX_ROWS];
+    const int count = hd_prof_collect(names, ms, fl, by, n, max_rows);
+    for (int v = 0; v < count; ++v) { rows[v].kernel = names[v]; rows[v].launches = n[v]; rows[v].total_ms = ms[v]; rows[v].flops = fl[v]; rows[v].bytes = by[v]; }
+    return count;
 }
 
 // ---- test-only entry points (include/hicdiff_hip_debug.h) ----
-}  // extern "C"
-extern unsigned long long* g_stamp;
-extern "C" {
-int hd_debug_stamp(int enable, unsigned long long out[8]) {
-    if (enable == 1) {
-        if (!g_stamp && hipMalloc((void**)&g_stamp, 64) != hipSuccess) return HD_EHIP;
-        (void)hipMemset(g_stamp, 0, 64);
-        return HD_OK;
-    }
-    if (!g_stamp || !out) return HD_EINVAL;
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(out, g_stamp, 64, hipMemcpyDeviceToHost);
-    if (enable == 0) { (void)hipFree(g_stamp); g_stamp = nullptr; }
-    return HD_OK;
-}
-
 int hd_debug_capture(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
     c->capture = enable != 0;

@@ -28,7 +28,6 @@ enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
 // hipGraph: f[0] = time value; ddpm: f[1..5] = recip, recipm1, coef1, coef2, sigma; ddrm: f[1..8] =
 // sqrt_at, sqrt_1m_at, sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC.
 struct StepParams { float f[12]; uint32_t step; uint32_t pad; uint64_t seed; uint64_t tile_off; };
-#define HD_PROF_VARIANTS 5
 
 enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2 };
 enum EpFlags {
@@ -77,8 +76,7 @@ void hd_set_error(const std::string& msg);
 
 void hd_prof_enable(bool on);
 bool hd_prof_is_on();
-void hd_prof_collect(double* ms, double* flops, double* bytes, long long* launches);   // HD_PROF_VARIANTS entries each
-const char* hd_prof_variant_name(int v);
+int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes, long long* launches, int max_rows);   // returns the row count
 
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);

@@ -176,9 +176,11 @@ int hd_randn(hd_ctx* ctx, float* out, int B, int S, uint64_t seed, uint64_t tile
 
 /* Per-launch HIP-event timing of the convolution kernels on their launch stream (process-wide;
  * not for use under stream capture).  hd_profile_enable(1) clears and starts recording,
- * hd_profile_read synchronises on the recorded events and returns, per kernel variant, the number
- * of launches, their summed duration and their summed ALGORITHMIC flops / bytes (each conv reads
- * its input once, writes its output once, reads its weights once). bench.py derives
+ * hd_profile_read synchronises on the recorded events and fills one row per kernel instantiation
+ * (named exactly as rocprofv3 --kernel-trace prints it, e.g. "conv_igemm_bf16x3_kernel<4, 1, 2, 2, 32, 6, 0, 9>")
+ * with the number of launches, their summed duration and their summed ALGORITHMIC flops / bytes (each
+ * conv reads its input once, writes its output once, reads its weights once); it returns the number of
+ * rows filled (<= max_rows, <= HD_PROFILE_MAX_ROWS) or a negative error. bench.py derives
  * roofline.achieved from it. */
 typedef struct {
     const char* kernel;
@@ -187,9 +189,9 @@ typedef struct {
     double flops;
     double bytes;
 } hd_profile_row;
-#define HD_PROFILE_ROWS 5
+#define HD_PROFILE_MAX_ROWS 96
 int hd_profile_enable(int enable);
-int hd_profile_read(hd_profile_row rows[HD_PROFILE_ROWS]);
+int hd_profile_read(hd_profile_row* rows, int max_rows);
 
 #ifdef __cplusplus
 }

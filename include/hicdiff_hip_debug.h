@@ -26,11 +26,6 @@ int hd_debug_capture(hd_ctx* ctx, int enable);
  * Returns HD_EINVAL when the label was not captured. */
 int hd_debug_read(hd_ctx* ctx, const char* label, float* dst, size_t n, int32_t dims[4]);
 
-/* Diagnostic builds only (make STAMP=1): per-phase s_memtime sums of the split-bf16 conv main loop,
- * summed over all waves: {weight staging, barrier wait, operand reads + MFMA, slice staging, epilogue,
- * whole kernel, waves, iterations}.  enable 1: reset, 2: read, 0: read and release. */
-int hd_debug_stamp(int enable, unsigned long long out[8]);
-
 #ifdef __cplusplus
 }
 #endif
