@@ -212,6 +212,7 @@ def main():
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),
             "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
             "conv_time_share": round(sum(r.total_ms for r in rows) * 1e-3 / (prof_steps * sec_per_step), 4),
+            "all_convs_frac": round(sum(r.flops for r in rows) / max(sum(r.total_ms for r in rows) * 1e-3, 1e-12) / 1e12 / peak, 4),
             "profiled_steps": prof_steps,
             "whole_step": {
                 "flop_frac_of_f32_mfma_peak": round(w["flop"] * B / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
