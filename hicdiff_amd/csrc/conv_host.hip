@@ -129,7 +129,8 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // (half the L2 -> LDS weight traffic of the K-heavy layers) and the activation window is double-buffered.
     static const bool big = !(getenv("HICDIFF_NO_CFG3"));
     int nthreads = 256;
-    if (pl.fast && wide && big && taps9 && a.H * a.W >= 4096) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
+    static const int cfg3_min_hw = getenv("HICDIFF_CFG3_MINHW") ? atoi(getenv("HICDIFF_CFG3_MINHW")) : 1024;   // measured on unet64 B=256: 4096 -> 16.07, 1024 -> 15.84, 256 -> 15.78 ms/step (but a loss at 64 tiles of 40x40), 64 -> 25.8
+    if (pl.fast && wide && big && taps9 && a.H * a.W >= cfg3_min_hw) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
     pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
     const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
     const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
