@@ -33,6 +33,7 @@ int launch_conv_bf16x3_ck16(ConvLaunch& L, hipStream_t st) {
         case IN_AFFINE_SILU: return launch_mode<IN_AFFINE_SILU>(L, st);
         case IN_AFFINE_SILU_E: return launch_mode<IN_AFFINE_SILU_E>(L, st);
         case IN_LAYERNORM: return launch_mode<IN_LAYERNORM>(L, st);
+        case IN_SOFTMAX32: hd_set_error("conv: the softmax loader needs 32-channel K slices"); return -1;
         default: return launch_mode<IN_NONE>(L, st);
     }
 }

@@ -8,10 +8,10 @@
 
 template <int MODE>
 static int launch_mode(ConvLaunch& L, hipStream_t st) {
-    const bool t9 = L.k.KH == 3 && L.k.KW == 3 && MODE != IN_LAYERNORM;
+    const bool t9 = L.k.KH == 3 && L.k.KW == 3 && MODE != IN_LAYERNORM && MODE != IN_SOFTMAX32;
     const int nt = L.cfg == 3 ? 512 : 256;
     const int need = (L.k.npx * 4 + nt - 1) / nt;
-    if constexpr (MODE != IN_LAYERNORM) {
+    if constexpr (MODE != IN_LAYERNORM && MODE != IN_SOFTMAX32) {
         if (t9) {
             switch (L.cfg) {
                 case 0: return need <= 3 ? launch_one(K32(2, 2, 2, 2, 3, 9), L, st) : launch_one(K32(2, 2, 2, 2, 5, 9), L, st);
@@ -34,6 +34,7 @@ int launch_conv_bf16x3_ck32(ConvLaunch& L, hipStream_t st) {
         case IN_AFFINE_SILU: return launch_mode<IN_AFFINE_SILU>(L, st);
         case IN_AFFINE_SILU_E: return launch_mode<IN_AFFINE_SILU_E>(L, st);
         case IN_LAYERNORM: return launch_mode<IN_LAYERNORM>(L, st);
+        case IN_SOFTMAX32: return launch_mode<IN_SOFTMAX32>(L, st);
         default: return launch_mode<IN_NONE>(L, st);
     }
 }

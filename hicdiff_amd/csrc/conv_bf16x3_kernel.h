@@ -78,6 +78,23 @@ __device__ __forceinline__ float4 xform4(float4 v, const char* pt, int ptv, floa
     return v;
 }
 
+// x over the four lanes of a quad (the four 8-channel items of one pixel's 32-channel slice): DPP quad_perm, no LDS
+__device__ __forceinline__ float quad_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ float quad_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false)); }
+
+// IN_SOFTMAX32: softmax over the 32 channels of the slice (LinearAttention's q.softmax(dim=-2), src/hicdiff.py:217;
+// one head = one K slice).  v0|v1 are this lane's 8 channels, the other 24 sit in the three neighbouring lanes.
+__device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
+    float m = fmaxf(fmaxf(fmaxf(v0.x, v0.y), fmaxf(v0.z, v0.w)), fmaxf(fmaxf(v1.x, v1.y), fmaxf(v1.z, v1.w)));
+    m = fmaxf(m, quad_xor1(m)); m = fmaxf(m, quad_xor2(m));
+    v0.x = __expf(v0.x - m); v0.y = __expf(v0.y - m); v0.z = __expf(v0.z - m); v0.w = __expf(v0.w - m);
+    v1.x = __expf(v1.x - m); v1.y = __expf(v1.y - m); v1.z = __expf(v1.z - m); v1.w = __expf(v1.w - m);
+    float s = (v0.x + v0.y) + (v0.z + v0.w) + (v1.x + v1.y) + (v1.z + v1.w);
+    s += quad_xor1(s); s += quad_xor2(s);
+    const float r = 1.f / s;
+    v0.x *= r; v0.y *= r; v0.z *= r; v0.w *= r; v1.x *= r; v1.y *= r; v1.z *= r; v1.w *= r;
+}
+
 // WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread;
 // NTAPS = 9: 3x3 filter, taps unrolled; NTAPS = 0: any filter (1x1, 2x2 stride 2, ...), taps in a loop.
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
@@ -89,7 +106,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
     constexpr int NW = (BN * (CK / 4)) / NT;           // 16-byte weight pieces per thread per slab
     constexpr int SLAB = BN * PITCH;                   // bytes of one weight slab in LDS
     constexpr bool XDB = NT == 512 && NTAPS == 9;      // two activation windows
-    constexpr int NV = MODE == IN_NONE ? 0 : MODE == IN_LAYERNORM ? 1 : MODE == IN_AFFINE_SILU ? 2 : 3;
+    constexpr int NV = MODE == IN_NONE || MODE == IN_SOFTMAX32 ? 0 : MODE == IN_LAYERNORM ? 1 : MODE == IN_AFFINE_SILU ? 2 : 3;
+    static_assert(MODE != IN_SOFTMAX32 || CK == 32, "the softmax loader works on 32-channel slices");
     static_assert(NW >= 1 && NW <= 4 && (NT == 256 || NT == 512), "bad tile");
     static_assert(NTAPS == 9 || NTAPS == 0, "taps are unrolled for 3x3 filters only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -214,11 +232,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
         const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
         *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = S##k;                                  \
     }
-    // slab k = (slice k / ntaps, tap k % ntaps); weights are stored [tap][slice][CoutPad][ROWB]
+    // slab k = (slice k / ntaps, tap k % ntaps); weights are stored [tap][slice][CoutPad][ROWB]; with per-sample
+    // weights (w_bstride != 0, one sample per tile) the image of sample b0
+    const char* wbase = reinterpret_cast<const char*>(p.wsplit) + (size_t)t.b0 * p.w_bstride;
     auto w_load = [&](auto set, int c, int tap) {
         if (ABL(256)) return;
         constexpr int S = decltype(set)::value;
-        const char* wsrc = reinterpret_cast<const char*>(p.wsplit) + ((size_t)(tap * nchunks + c) * p.CoutPad + t.n0) * ROWB;
+        const char* wsrc = wbase + ((size_t)(tap * nchunks + c) * p.CoutPad + t.n0) * ROWB;
         if constexpr (S == 0) { HD_WLOAD(w, 0) HD_WLOAD(w, 1) HD_WLOAD(w, 2) HD_WLOAD(w, 3) }
         else if constexpr (S == 1) { HD_WLOAD(v, 0) HD_WLOAD(v, 1) HD_WLOAD(v, 2) HD_WLOAD(v, 3) }
         else { HD_WLOAD(u, 0) HD_WLOAD(u, 1) HD_WLOAD(u, 2) HD_WLOAD(u, 3) }
@@ -246,8 +266,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
     auto x_stage = [&](int j, int c, char* xdst) {
         if (ABL(64)) return;
         const char* pt = ptab + (c & 1) * pt_stride + it_pt[j];
-        const float4 v0 = xform4<MODE>(xr[j][0], pt, ptv, ln_mu[j], ln_rs[j]);
-        const float4 v1 = xform4<MODE>(xr[j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
+        float4 v0 = xform4<MODE>(xr[j][0], pt, ptv, ln_mu[j], ln_rs[j]);
+        float4 v1 = xform4<MODE>(xr[j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
+        if constexpr (MODE == IN_SOFTMAX32) softmax32(v0, v1);
         uint4 hi, lo;
         split8(v0, v1, hi, lo);
         if (it_pad[j]) { hi = make_uint4(0, 0, 0, 0); lo = hi; }   // zero padding is applied AFTER the transform
@@ -435,7 +456,7 @@ static int launch_one(K kernel, const char* name, ConvLaunch& L, hipStream_t st,
 // kernel-side loader mode of a launch
 static inline int conv_kernel_mode(const ConvLaunch& L) {
     if (L.k.in_mode == IN_AFFINE_SILU) return L.k.inE ? IN_AFFINE_SILU_E : IN_AFFINE_SILU;
-    return L.k.in_mode;
+    return L.k.in_mode;   // IN_NONE, IN_LAYERNORM, IN_SOFTMAX32
 }
 
 // Largest window (in staged 8-channel items per thread) a launch may use; conv_host.hip plans the tile inside

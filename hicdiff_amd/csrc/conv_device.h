@@ -20,6 +20,7 @@ struct ConvKArgs {
     const float* ln_stats; const float* ln_g;
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
+    const float* ep_ln_g; unsigned long long w_bstride;
     float* out; float* gn_part; int gn_slots;
     int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
@@ -170,7 +171,39 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         }
         __syncthreads();
         if (nvalid > 0 && !(p.ablate & 128)) {
-            if (p.ep == 0 && vec) {
+            if (p.ep & EP_LN_RES) {
+                // Whole rows live in this workgroup (Cout == BN, checked by the launcher): channel LayerNorm of the
+                // row (biased variance, eps 1e-5: src/hicdiff.py:99-108), gain, + residual.  A row is held by CQ
+                // consecutive lanes (4 channels each); sums travel by xor shuffles inside that group.
+                const float4 g4 = *reinterpret_cast<const float4*>(p.ep_ln_g + n);
+                auto rsum = [](float x) {
+#pragma unroll
+                    for (int m = 1; m < CQ; m <<= 1) x += __shfl_xor(x, m, 64);
+                    return x;
+                };
+                auto fetch_res = [&](int pass) {
+                    const int lr = pass * RPP + rg;
+                    const int pix = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
+                    return *reinterpret_cast<const float4*>(p.res + (size_t)(pix < 0 ? 0 : pix) * p.Cout + n);
+                };
+                float4 n_rr = fetch_res(0);
+#pragma unroll 2
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int lr = pass * RPP + rg;
+                    const int pix = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
+                    const float4 rr = n_rr;
+                    if (pass + 1 < NPASS) n_rr = fetch_res(pass + 1);
+                    const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                    float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                    const float mean = rsum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] -= mean;
+                    const float var = rsum(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]) * (1.f / BN);
+                    const float rs = rsqrtf(var + 1e-5f);
+                    const f32x4 o4 = {v[0] * rs * g4.x + rr.x, v[1] * rs * g4.y + rr.y, v[2] * rs * g4.z + rr.z, v[3] * rs * g4.w + rr.w};
+                    if (pix >= 0) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                }
+            } else if (p.ep == 0 && vec) {
                 // Fast path (every GroupNorm'd conv): no global load in the loop.  vmcnt retires in issue order, so a
                 // loop that mixes loads with stores makes every load wait for the previous pass's STORE round trip
                 // (measured: half of the kernel on the 64-channel full-resolution layers); here stores just stream.

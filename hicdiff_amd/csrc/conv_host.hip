@@ -80,9 +80,9 @@ struct TileGeom { int TB, TH, TW; };
 
 // Pick the TB x TH x TW output window (<= BM pixels) that wastes the fewest MFMA rows, then the
 // fewest staged halo pixels.  Small feature maps take whole images (TB > 1).
-static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int stride, int max_px) {
-    static std::map<std::tuple<int, int, int, int, int, int, int, int>, TileGeom> cache;
-    const auto key = std::make_tuple(B, H, W, BM, KH, KW, stride, max_px);
+static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int stride, int max_px, bool one_sample) {
+    static std::map<std::tuple<int, int, int, int, int, int, int, int, bool>, TileGeom> cache;
+    const auto key = std::make_tuple(B, H, W, BM, KH, KW, stride, max_px, one_sample);
     auto hit = cache.find(key);
     if (hit != cache.end()) return hit->second;
     TileGeom best{1, 1, 1};
@@ -90,7 +90,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
     for (int tw = 1; tw <= W && tw <= BM; ++tw) {
         for (int th = 1; th <= H && th * tw <= BM; ++th) {
             int tb = 1;
-            if (th == H && tw == W) { tb = BM / (H * W); if (tb > B) tb = B; if (tb > 32) tb = 32; if (tb < 1) tb = 1; }   // 32: loader-parameter table of the bf16x3 kernel
+            if (th == H && tw == W && !one_sample) { tb = BM / (H * W); if (tb > B) tb = B; if (tb > 32) tb = 32; if (tb < 1) tb = 1; }   // 32: loader-parameter table of the bf16x3 kernel
             long lh = (long)(th - 1) * stride + KH, lw = (long)(tw - 1) * stride + KW;
             long npx = tb * lh * lw;
             if (npx > max_px) continue;
@@ -122,7 +122,7 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // the batch size: GroupNorm partial sums follow the tiling, and a tile's result has to be bit-identical
     // whether it is sampled alone, in a batch of 256 or on another rank.
     const int ntaps = a.cw.KH * a.cw.KW;
-    const bool ln = a.in_mode == IN_LAYERNORM;
+    const bool ln = a.in_mode == IN_LAYERNORM || a.in_mode == IN_SOFTMAX32;   // loaders that exist in the any-filter kernels only
     const bool taps9 = a.cw.KH == 3 && a.cw.KW == 3 && !ln;      // kernels with unrolled taps
     if (pl.fast && !wide && a.H * a.W >= 1024 && (taps9 || ntaps == 1)) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
     // 256 x 128 tile with 8 waves (4 x 2), one workgroup per CU: the two wave groups share every weight slab
@@ -137,13 +137,13 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // bf16x3: one sink row per window; the 8-wave variant double-buffers the window; loader-parameter table
     // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest possible)
     const int nxb = pl.fast && pl.cfg == 3 ? 2 : 1;
-    const int nv = !pl.fast || a.in_mode == IN_NONE ? 0 : ln ? 1 : a.inE ? 3 : 2;
+    const int nv = !pl.fast || a.in_mode == IN_NONE || a.in_mode == IN_SOFTMAX32 ? 0 : ln ? 1 : a.inE ? 3 : 2;
     const int tb_max = std::max(1, std::min(32, pl.BM / std::max(1, a.H * a.W)));   // TB > 1 only when whole images fit in the tile
     const size_t pt_reserve = (size_t)2 * nv * ((ln ? 1 : tb_max) * pl.ck / 4 + 1) * 16;
     long max_px = (long)((budget - wbytes - pt_reserve - 2 * pl.BM * 4 - (pl.fast ? nxb * pl.pitch : 0)) / (nxb * pl.pitch + 8));
     if (pl.fast) max_px = std::min<long>(max_px, (long)nthreads * conv_bf16x3_max_items(pl.cfg, pl.ck, taps9, ln) / (pl.ck / 8));
     if (max_px > 512) max_px = 512;
-    pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px);
+    pl.g = pick_geom(a.B, a.H, a.W, pl.BM, a.cw.KH, a.cw.KW, a.stride, (int)max_px, a.w_bstride != 0);
     const int LH = (pl.g.TH - 1) * a.stride + a.cw.KH, LW = (pl.g.TW - 1) * a.stride + a.cw.KW;
     const int npx = pl.g.TB * LH * LW, npx4 = (npx + 3) & ~3;
     const size_t stage = (size_t)(pl.BM / 2) * (pl.BN + 4) * 4;  // epilogue staging (TM = 2 rounds) overlays the operand buffers
@@ -172,6 +172,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ln_stats = a.ln_stats; k.ln_g = a.ln_g;
     k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
     k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
+    k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride;
     k.out = a.out;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
@@ -182,7 +183,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
         hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");
         return -1;
     }
+    if ((a.in_mode == IN_SOFTMAX32 || a.w_bstride) && !pl.fast) { hd_set_error("conv: the softmax loader / per-sample weights exist in the split-bf16 kernel only"); return -1; }
+    if (a.in_mode == IN_SOFTMAX32 && (pl.ck != 32 || a.C1)) { hd_set_error("conv: the softmax loader needs 32-channel slices of one tensor"); return -1; }
+    if ((a.ep & EP_LN_RES) && (k.Cout != pl.BN || a.ep != EP_LN_RES || !a.ep_ln_g || !a.res)) {
+        hd_set_error("conv: the LayerNorm epilogue needs Cout == tile width (64 or 128), a gain and a residual, and no other epilogue"); return -1;
+    }
     const TileGeom g = pl.g;
+    if (a.w_bstride && g.TB != 1) { hd_set_error("conv: per-sample weights need one sample per tile"); return -1; }
     k.TB = g.TB; k.TH = g.TH; k.TW = g.TW;
     k.LH = (g.TH - 1) * a.stride + k.KH; k.LW = (g.TW - 1) * a.stride + k.KW;
     k.npx = g.TB * k.LH * k.LW;

@@ -436,18 +436,28 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
     q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
     HD_TRY(run_conv(r, q));
     r.free(stats);
-    Act att; HD_TRY(r.act(H, W, 128, &att));
+    // q side, fused form (split-bf16 arithmetic, feature maps of >= 256 pixels so a conv tile never mixes samples):
+    // the context is folded into to_out's weight per sample and the q-softmax runs in to_out's loader, so neither the
+    // attention output nor (for C = 64 / 128, where a tile holds whole channel rows) the pre-LayerNorm tensor exists.
+    const bool qfuse = fused && HW >= 256 && w.out.ck == 32;
+    const bool lnfuse = qfuse && (C == 64 || C == 128);
+    Act att{};
+    if (!qfuse || r.dry) HD_TRY(r.act(H, W, 128, &att));
+    unsigned short* wfold = nullptr;
+    const size_t wfold_bytes = (size_t)heads * w.out.CoutPad * 64 * sizeof(unsigned short);   // per sample
     if (fused) {
         const int nsplit = linattn_kv_nsplit(HW);
         const size_t slots = (size_t)r.B * heads * nsplit;
         float *ctx, *scr;
         HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
         HD_TRY(r.alloc(std::max(slots * (32 + 32 + 32 * 32), linattn_scratch_floats(r.B, HW, heads)), &scr));
+        if (qfuse || r.dry) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
         if (!r.dry) {
             float* pmax = scr; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
             HD_TRY(launch_linattn_kv_fused(x.p, w.wkv, r.B, HW, C, pmax, psum, pctx, r.st));
             HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nsplit, HW, ctx, r.st));
-            HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st));
+            if (qfuse) HD_TRY(launch_linattn_fold_out(w.out.w, ctx, r.B, w.out.CoutPad, wfold, r.st));
+            else HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st));
         }
         r.free(ctx); r.free(scr);
     } else if (w.linear) {
@@ -461,21 +471,32 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
     } else if (!r.dry) {
         HD_TRY(launch_attn_full(qkv.p, r.B, HW, heads, att.p, r.st));
     }
-    r.free(qkv);
+    if (!qfuse) r.free(qkv);
     HD_TRY(r.act(H, W, C, out));
     ConvArgs o;
     o.in0 = att.p; o.C0 = 128; o.B = r.B; o.H = H; o.W = W; o.IH = H; o.IW = W; o.stride = 1; o.pad = 0; o.cw = w.out;
+    if (qfuse && !r.dry) {
+        o.in0 = qkv.p; o.in_mode = IN_SOFTMAX32; o.cw.wsplit = wfold; o.w_bstride = wfold_bytes;
+    }
     if (w.linear) {
-        Act y; HD_TRY(r.act(H, W, C, &y));
-        o.out = y.p;
-        HD_TRY(run_conv(r, o));
-        if (!r.dry) HD_TRY(launch_ln_residual(y.p, w.out_g, x.p, out->p, P, C, r.st));
-        r.free(y);
+        Act y{};
+        if (!lnfuse || r.dry) HD_TRY(r.act(H, W, C, &y));
+        if (lnfuse && !r.dry) {
+            o.out = out->p; o.ep = EP_LN_RES; o.ep_ln_g = w.out_g; o.res = x.p;
+            HD_TRY(run_conv(r, o));
+        } else {
+            o.out = y.p;
+            HD_TRY(run_conv(r, o));
+            if (!r.dry) HD_TRY(launch_ln_residual(y.p, w.out_g, x.p, out->p, P, C, r.st));
+        }
+        if (y.p) r.free(y);
     } else {
         o.out = out->p; o.ep = EP_RES; o.alpha = 1.f; o.res = x.p;
         HD_TRY(run_conv(r, o));
     }
-    r.free(att);
+    if (qfuse) r.free(qkv);
+    if (wfold) r.free((float*)wfold);
+    if (att.p) r.free(att);
     return 0;
 }
 
@@ -845,6 +866,35 @@ int hd_profile_read(hd_profile_row* rows, int max_rows) {
 }
 
 // ---- test-only entry points (include/hicdiff_hip_debug.h) ----
+int hd_debug_linattn_out(const float* q, const float* ctx, const float* wout, const float* bias, const float* g, const float* res,
+                         int B, int H, int W, int C, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!q || !ctx || !wout || !g || !res || !out || C % 64) return HD_EINVAL;
+    ConvW cw; cw.KH = cw.KW = 1; cw.Cin = 128; cw.Cout = C; cw.CoutPad = C; cw.ck = 32; cw.bias = const_cast<float*>(bias);
+    void *pw = nullptr, *pf = nullptr, *py = nullptr;
+    const size_t fold_bytes = (size_t)4 * C * 64 * sizeof(unsigned short);
+    if (hipMalloc(&pw, (size_t)128 * C * sizeof(float)) != hipSuccess || hipMalloc(&pf, (size_t)B * fold_bytes) != hipSuccess) return HD_EHIP;
+    cw.w = (float*)pw;
+    int rc = launch_pack_conv(wout, cw.w, C, 128, 1, 1, C, 0, 0, st);
+    if (rc == 0) rc = launch_linattn_fold_out(cw.w, ctx, B, C, (unsigned short*)pf, st);
+    ConvArgs a;
+    a.in0 = q; a.C0 = 128; a.B = B; a.H = H; a.W = W; a.IH = H; a.IW = W; a.stride = 1; a.pad = 0; a.cw = cw;
+    a.cw.wsplit = (unsigned short*)pf; a.w_bstride = fold_bytes; a.in_mode = IN_SOFTMAX32; a.precision = HD_PREC_BF16X3;
+    const size_t P = (size_t)B * H * W;
+    if (C == 64 || C == 128) {
+        a.out = out; a.ep = EP_LN_RES; a.ep_ln_g = g; a.res = res;
+        if (rc == 0) rc = launch_conv(a, st, nullptr);
+    } else {
+        if (hipMalloc(&py, P * C * sizeof(float)) != hipSuccess) rc = HD_EHIP;
+        a.out = (float*)py;
+        if (rc == 0) rc = launch_conv(a, st, nullptr);
+        if (rc == 0) rc = launch_ln_residual((const float*)py, g, res, out, P, C, st);
+    }
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(pw); (void)hipFree(pf); if (py) (void)hipFree(py);
+    return rc;
+}
+
 int hd_debug_capture(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
     c->capture = enable != 0;

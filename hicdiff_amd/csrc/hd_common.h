@@ -29,12 +29,13 @@ enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
 // sqrt_at, sqrt_1m_at, sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC.
 struct StepParams { float f[12]; uint32_t step; uint32_t pad; uint64_t seed; uint64_t tile_off; };
 
-enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2 };
+enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2, IN_SOFTMAX32 = 4 };   // 4: softmax over every 32-channel group (LinearAttention q, src/hicdiff.py:217); bf16x3 kernel only
 enum EpFlags {
     EP_FILM_SILU = 1,      // v = silu(v * (scale[b][n] + 1) + shift[b][n])       (hicedrn block, first conv)
     EP_ADD_SILU = 2,       // v = silu(v + shift[b][n])                            (hicedrn SR3 block)
     EP_RES = 4,            // v = alpha * v + res[pix][n]
-    EP_RES_AFFINE_SILU = 8 // v = v + silu(res[pix][n] * resA[b][n] + resB[b][n]) (UNet block tail through res_conv)
+    EP_RES_AFFINE_SILU = 8, // v = v + silu(res[pix][n] * resA[b][n] + resB[b][n]) (UNet block tail through res_conv)
+    EP_LN_RES = 16         // v = LayerNorm_channels(v) * ep_ln_g[n] + res[pix][n]   (LinearAttention to_out tail, src/hicdiff.py:207-210,64-70); needs Cout == tile width
 };
 
 struct ConvArgs {
@@ -56,6 +57,8 @@ struct ConvArgs {
     const float* epScale = nullptr; const float* epShift = nullptr; int ep_bstride = 0;
     float alpha = 1.f;
     const float* res = nullptr; const float* resA = nullptr; const float* resB = nullptr; int res_bstride = 0;
+    const float* ep_ln_g = nullptr;   // EP_LN_RES: LayerNorm gain [Cout]
+    size_t w_bstride = 0;             // bf16x3 only: bytes between per-sample images of cw.wsplit (0: one shared weight); forces one sample per tile
     float* out = nullptr;
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
     // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
@@ -112,6 +115,7 @@ int launch_pack_kv(const float* wqkv, const float* g, int C, unsigned short* dst
 int linattn_kv_nsplit(int HW);
 int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
                             hipStream_t st);
+int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,

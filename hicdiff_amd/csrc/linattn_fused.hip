@@ -221,3 +221,37 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
     if (e != hipSuccess) { hd_set_error(std::string("linattn_kv_fused: ") + hipGetErrorString(e)); return -3; }
     return 0;
 }
+
+// ---- q side: the context folded into to_out ----------------------------------------------------------------
+// out[n][h*32+e] = scale * sum_d ctx[h][d][e] * softmax_d(q)[n][h*32+d] followed by the 1x1 to_out convolution is one
+// 1x1 convolution of softmax_d(q) with the per-sample weight  W'_b[o][h*32+d] = scale * sum_e Wout[o][h*32+e] * ctx_b[h][d][e]
+// (src/hicdiff.py:217-226).  This kernel writes W'_b in the split-bf16 slab layout of the conv kernel
+// ([slice = head][CoutPad][32 hi | 32 lo]); the conv's loader then applies the softmax (IN_SOFTMAX32).
+__global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __restrict__ wout, const float* __restrict__ ctx, int CoutPad,
+                                                               unsigned short* __restrict__ dst) {
+    constexpr int D = 32;
+    __shared__ float cs[D][D + 1];
+    const int bh = blockIdx.x, h = bh & 3, tid = threadIdx.x;       // heads = 4
+    for (int i = tid; i < D * D; i += 256) cs[i / D][i % D] = ctx[(size_t)bh * D * D + i];
+    __syncthreads();
+    const float* w = wout + (size_t)h * D * CoutPad;                 // packed fp32 [Cin = 128][CoutPad]
+    unsigned short* out = dst + (size_t)bh * CoutPad * 2 * D;        // [b][head][CoutPad][64]
+    for (int i = tid; i < CoutPad * D; i += 256) {
+        const int o = i % CoutPad, d = i / CoutPad;
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; ++e) acc += w[(size_t)e * CoutPad + o] * cs[d][e];
+        acc *= 0.17677669529663687f;                                 // dim_head ** -0.5
+        const __bf16 hi = (__bf16)acc;
+        const __bf16 lo = (__bf16)(acc - (float)hi);
+        out[(size_t)o * 2 * D + d] = __builtin_bit_cast(unsigned short, hi);
+        out[(size_t)o * 2 * D + D + d] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+
+int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st) {
+    hipLaunchKernelGGL(linattn_fold_out_kernel, dim3(B * 4), dim3(256), 0, st, wout_packed, ctx, CoutPad, dst);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hd_set_error(std::string("linattn_fold_out launch: ") + hipGetErrorString(e)); return -3; }
+    return 0;
+}

@@ -20,6 +20,13 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
                   const float* bias, int Cout, int K, int mode, const float* A, const float* Bv, const float* E,
                   float* out, void* stream);
 
+/* The fused q side of LinearAttention (src/hicdiff.py:217-226,207-210): out = LayerNorm(to_out(einsum(context,
+ * softmax_d(q) * scale))) * g + res, run as the engine runs it: the context is folded into to_out's weight per
+ * sample, the softmax is the conv's loader transform, LayerNorm + residual its epilogue (C = 64 / 128) or a second
+ * kernel.  q: NHWC [B,H,W,128] (4 heads x 32); ctx: [B,4,32,32] (d, e); wout: torch layout [C,128,1,1]; H*W >= 256. */
+int hd_debug_linattn_out(const float* q, const float* ctx, const float* wout, const float* bias, const float* g, const float* res,
+                         int B, int H, int W, int C, float* out, void* stream);
+
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.

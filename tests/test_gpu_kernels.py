@@ -138,3 +138,40 @@ def test_large_grid_is_correct_and_bitwise_reproducible(mode, prec):
     outs = [fn() for _ in range(3)]
     assert rel_err(ref, outs[0]) < PRECS[prec]
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("B,S,Cc", [(2, 16, 64), (3, 16, 128), (2, 16, 256), (32, 64, 64), (48, 32, 128)])
+def test_linear_attention_q_side_fused(B, S, Cc):
+    """softmax_d(q) -> context -> to_out -> LayerNorm -> + x as ONE convolution (context folded into the weight per
+    sample, softmax in the loader, LayerNorm + residual in the epilogue) against the reference formulation
+    (src/hicdiff.py:217-226, 99-108, 64-70); the large cases also have to repeat bit-for-bit."""
+    lib = _lib()
+    lib.hd_debug_linattn_out.restype = C.c_int
+    lib.hd_debug_linattn_out.argtypes = [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+    heads, D = 4, 32
+    q = rnd(1, B, heads * D, S, S) * 1.5
+    ctx = rnd(2, B, heads, D, D) * 0.3
+    wout, bias, g = rnd(3, Cc, heads * D, 1, 1) / 11, rnd(4, Cc) * 0.1, rnd(5, Cc) * 0.2 + 1
+    res = rnd(6, B, Cc, S, S)
+    qs = q.view(B, heads, D, S * S).softmax(dim=-2) * D ** -0.5
+    o = torch.einsum("bhde,bhdn->bhen", ctx, qs).reshape(B, heads * D, S, S)
+    y = F.conv2d(o, wout, bias)
+    mean, var = y.mean(dim=1, keepdim=True), y.var(dim=1, unbiased=False, keepdim=True)
+    ref = (y - mean) * (var + 1e-5).rsqrt() * g.view(1, -1, 1, 1) + res
+
+    def run():
+        dev = "cuda"
+        t = lambda a: a.to(dev).contiguous()
+        qd, cd, wd, bd, gd, rd = t(nhwc(q)), t(ctx), t(wout), t(bias), t(g), t(nhwc(res))
+        out = torch.full((B, S, S, Cc), float("nan"), device=dev)
+        p = lambda a: C.c_void_p(a.data_ptr())
+        rc = lib.hd_debug_linattn_out(p(qd), p(cd), p(wd), p(bd), p(gd), p(rd), B, S, S, Cc, p(out),
+                                      C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out.permute(0, 3, 1, 2).cpu()
+
+    outs = [run() for _ in range(3 if B >= 32 else 1)]
+    assert rel_err(ref, outs[0]) < 1e-4
+    for o2 in outs[1:]:
+        assert torch.equal(outs[0], o2)
