@@ -848,6 +848,12 @@ int hd_randn(hd_ctx* c, float* out, int B, int S, uint64_t seed, uint64_t tile_o
     return keep_err(c, launch_randn(out, B, S, seed, tile_offset, step, (hipStream_t)stream));
 }
 
+int hd_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
+                    void* stream) {
+    if (!pred || !target || !partial || !sums || B < 1) return HD_EINVAL;
+    return launch_tile_metrics(pred, target, B, S, rescale, partial, sums, ssim_each, (hipStream_t)stream) == 0 ? HD_OK : HD_EINVAL;
+}
+
 int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {

@@ -116,6 +116,8 @@ int linattn_kv_nsplit(int HW);
 int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
                             hipStream_t st);
 int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st);
+int launch_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
+                        hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,

@@ -722,3 +722,80 @@ int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st)
     hipLaunchKernelGGL(set_step_params_kernel, dim3(1), dim3(1), 0, st, dst, v);
     return check_launch("set_step_params");
 }
+
+// ---- tile-quality metrics (src/Utils/loss/SSIM.py:17-37, src/Utils/stard_metrics.py:146-160) --------------------
+// One workgroup per tile.  Both tiles are staged in LDS (optionally mapped from [-1,1] to [0,1] with a clamp:
+// inverse_data_transform('rescaled'), src/datasets/__init__.py:214-223); every thread walks its pixels, forms the five
+// 11x11 Gaussian-window sums (zero padding, fp32, row-major like a direct convolution) and the SSIM value, and
+// accumulates seven sums in double.  partial[b][8] = {sum (p-t)^2, sum ssim, sum t, sum p, sum t^2, sum p^2, sum p*t, S*S};
+// a second single-workgroup kernel adds the tiles up in index order (deterministic).
+__constant__ unsigned int kSsimWindowBits[11] = {0x3a86cab6u, 0x3bf8ff01u, 0x3d13758cu, 0x3ddff87fu, 0x3e5a1e1fu, 0x3e8832b0u,
+                                                0x3e5a1e1fu, 0x3ddff87fu, 0x3d13758cu, 0x3bf8ff01u, 0x3a86cab6u};   // gaussian(11, 1.5) as float32
+
+__global__ __launch_bounds__(256) void tile_metrics_kernel(const float* __restrict__ pred, const float* __restrict__ target, int S,
+                                                           int rescale, double* __restrict__ partial) {
+    extern __shared__ float tm_lds[];
+    float* xs = tm_lds;            // pred   [S][S]
+    float* ys = tm_lds + S * S;    // target [S][S]
+    __shared__ float w1[11];
+    __shared__ double red[4][8];
+    const int b = blockIdx.x, tid = threadIdx.x, n = S * S;
+    if (tid < 11) w1[tid] = __builtin_bit_cast(float, kSsimWindowBits[tid]);
+    for (int i = tid; i < n; i += 256) {
+        float x = pred[(size_t)b * n + i], y = target[(size_t)b * n + i];
+        if (rescale) { x = fminf(fmaxf((x + 1.0f) / 2.0f, 0.0f), 1.0f); y = fminf(fmaxf((y + 1.0f) / 2.0f, 0.0f), 1.0f); }
+        xs[i] = x; ys[i] = y;
+    }
+    __syncthreads();
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        const int py = i / S, px = i - py * S;
+        float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+        for (int dy = 0; dy < 11; ++dy) {
+            const int yy = py + dy - 5;
+            if (yy < 0 || yy >= S) continue;
+            for (int dx = 0; dx < 11; ++dx) {
+                const int xx = px + dx - 5;
+                if (xx < 0 || xx >= S) continue;
+                const float w = w1[dy] * w1[dx];
+                const float a = xs[yy * S + xx], c = ys[yy * S + xx];
+                mu1 += w * a; mu2 += w * c; e11 += w * (a * a); e22 += w * (c * c); e12 += w * (a * c);
+            }
+        }
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+        const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu1_mu2;
+        const float C1 = 0.0001f, C2 = 0.0009f;
+        const float v = ((2.f * mu1_mu2 + C1) * (2.f * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+        const float x = xs[i], y = ys[i], d = x - y;
+        acc[0] += (double)(d * d); acc[1] += (double)v; acc[2] += (double)y; acc[3] += (double)x;
+        acc[4] += (double)y * y; acc[5] += (double)x * x; acc[6] += (double)x * y;
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        double v = acc[k];
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+        if ((tid & 63) == 0) red[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid < 7) partial[(size_t)b * 8 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid == 7) partial[(size_t)b * 8 + 7] = (double)n;
+}
+
+__global__ __launch_bounds__(64) void tile_metrics_reduce_kernel(const double* __restrict__ partial, int B, int S, double* __restrict__ sums,
+                                                                 float* __restrict__ ssim_each) {
+    const int tid = threadIdx.x;
+    if (tid < 8) {
+        double a = 0.0;
+        for (int b = 0; b < B; ++b) a += partial[(size_t)b * 8 + tid];
+        sums[tid] = a;
+    }
+    if (ssim_each) for (int b = tid; b < B; b += 64) ssim_each[b] = (float)(partial[(size_t)b * 8 + 1] / (double)(S * S));
+}
+
+int launch_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
+                        hipStream_t st) {
+    if (S < 1 || S > 128) { hd_set_error("tile_metrics: tile size must be 1..128"); return -1; }
+    hipLaunchKernelGGL(tile_metrics_kernel, dim3(B), dim3(256), (size_t)2 * S * S * sizeof(float), st, pred, target, S, rescale, partial);
+    hipLaunchKernelGGL(tile_metrics_reduce_kernel, dim3(1), dim3(64), 0, st, partial, B, S, sums, ssim_each);
+    return check_launch("tile_metrics");
+}

@@ -172,6 +172,19 @@ int hd_loss_per_sample(hd_ctx* ctx, const float* pred, const float* target, int 
 int hd_randn(hd_ctx* ctx, float* out, int B, int S, uint64_t seed, uint64_t tile_offset,
              uint32_t step, void* stream);
 
+/* ---- evaluation (the callers next to the path) ---------------------- */
+
+/* Tile-quality sums of the reference's evaluation loop: SSIM (src/Utils/loss/SSIM.py:17-37: 11x11 Gaussian window,
+ * sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) and the raw moments behind mse / psnr / snr / pcc
+ * (src/Utils/stard_metrics.py:146-160).  pred, target: (B,1,S,S) device tensors, S <= 128.  rescale != 0 first maps
+ * [-1,1] tiles to [0,1] with a clamp (inverse_data_transform('rescaled'), src/datasets/__init__.py:214-223);
+ * rescale == 0 takes the values as they are (the ssim(img1, img2) call itself).
+ *   sums (device, 8 doubles): sum (p-t)^2, sum of the SSIM map, sum t, sum p, sum t^2, sum p^2, sum p*t, B*S*S
+ *   ssim_each (device, B floats, may be NULL): per-tile mean of the SSIM map (size_average=False)
+ *   partial: device scratch, B*8 doubles.  No context needed; only enqueues on the stream; deterministic. */
+int hd_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
+                    void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-launch HIP-event timing of the convolution kernels on their launch stream (process-wide;

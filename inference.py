@@ -52,6 +52,7 @@ def create_parser():
     p.add_argument("--outdir", default=os.path.join(ROOT, "Outputs_diff"))
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3")
+    p.add_argument("--metrics", action="store_true", help="report mse / psnr / ssim / snr / pcc of predict vs target (GPU, stard_metrics.py:146-160)")
     return p
 
 
@@ -139,6 +140,15 @@ def main(argv=None):
         np.save(os.path.join(out, "noisy"), lq.numpy())
         np.save(os.path.join(out, "inds"), np.arange(n, dtype=np.int64))
         print(f"[inference] {n} tiles of 1x{S}x{S} -> {out}")
+        if args.metrics:
+            from hicdiff_amd.Utils.metrics import MetricLog
+            log, base = MetricLog(), MetricLog()
+            for b0 in range(0, n, bs):
+                log.update(predict[b0:b0 + bs], hq[b0:b0 + bs].to(device))
+                base.update(lq[b0:b0 + bs].to(device), hq[b0:b0 + bs].to(device))
+            fmt = lambda r: f"mse {r['mse'] / r['nsamples']:.5f}, " + ", ".join(f"{k} {r[k]:.4f}" for k in ("psnr", "ssim", "pcc"))
+            print(f"[inference] predict vs target: {fmt(log.r)}")
+            print(f"[inference] noisy   vs target: {fmt(base.r)}")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -350,7 +350,39 @@ def case_losses():
     save("losses", **out)
 
 
+def case_metrics():
+    """src/Utils/loss/SSIM.py (the reference's own module) and the per-batch formulas of src/Utils/stard_metrics.py:146-160
+    (restated here line by line because that file cannot be imported: pyrootutils / processdata / matplotlib)."""
+    from math import log10
+    from scipy.stats import pearsonr
+    from src.Utils.loss import SSIM as RS          # reference
+    from oracle import metrics as OM
+    out = {}
+    for tag, B, S, noise in (("s40", 3, 40, 0.15), ("s64", 2, 64, 0.05), ("far", 2, 64, 1.0)):
+        hq = tiles(41, B, S) ** 3
+        pr = (hq + noise * gauss(42, hq.shape)).clamp(-1.2, 1.2)          # also exercises the [0,1] clamp
+        o, h = torch.clamp((pr + 1.0) / 2.0, 0.0, 1.0), torch.clamp((hq + 1.0) / 2.0, 0.0, 1.0)   # inverse_data_transform('rescaled')
+        ssim_mean = RS.ssim(o, h)
+        ssim_each = RS.ssim(o, h, size_average=False)
+        ssim_mod = RS.SSIM()(o, h)
+        mse = ((o - h) ** 2).mean()
+        snr = h.sum() / ((h - o) ** 2).sum().sqrt()
+        pcc = pearsonr(o.flatten().numpy(), h.flatten().numpy())[0]
+        check(f"ssim {tag}", ssim_mean, OM.ssim(o, h), tol=1e-6)
+        check(f"ssim each {tag}", ssim_each, OM.ssim(o, h, size_average=False), tol=1e-6)
+        assert abs(float(ssim_mod) - float(ssim_mean)) < 1e-7
+        om = OM.batch_metrics(pr, hq)
+        assert abs(om["mse"] - float(mse)) <= 1e-7 * max(float(mse), 1e-9) + 1e-10 and abs(om["snr"] - float(snr)) <= 1e-5 * abs(float(snr))
+        assert abs(om["pcc"] - float(pcc)) < 1e-6
+        out[f"{tag}_pred"], out[f"{tag}_target"] = pr, hq
+        out[f"{tag}_ssim"], out[f"{tag}_ssim_each"], out[f"{tag}_mse"], out[f"{tag}_snr"], out[f"{tag}_pcc"] = ssim_mean, ssim_each, mse, snr, pcc
+        out[f"{tag}_psnr"] = 10 * log10(1 / float(mse))
+    out["window"] = RS.create_window(11, 1)
+    save("metrics", **out)
+
+
 CASES = {
+    "metrics": case_metrics,
     "inventory": case_param_inventory,
     "schedules": case_schedules,
     "eps": case_eps,

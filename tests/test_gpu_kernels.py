@@ -175,3 +175,49 @@ def test_linear_attention_q_side_fused(B, S, Cc):
     assert rel_err(ref, outs[0]) < 1e-4
     for o2 in outs[1:]:
         assert torch.equal(outs[0], o2)
+
+
+@pytest.mark.parametrize("tag", ["s40", "s64", "far"])
+def test_tile_metrics_golden(tag):
+    """hd_tile_metrics (SSIM + the moments behind mse / psnr / snr / pcc) against the values produced by the reference's
+    own SSIM module and evaluation formulas (tests/golden/make_golden.py::case_metrics) and against the oracle."""
+    import os
+    import numpy as np
+    from _util import GOLDEN
+    from hicdiff_amd.Utils import metrics as M
+    from hicdiff_amd.Utils.loss.SSIM import SSIM, ssim
+    from oracle import metrics as OM
+    g = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    pr, hq = torch.from_numpy(g[f"{tag}_pred"]).cuda(), torch.from_numpy(g[f"{tag}_target"]).cuda()
+    m = M.batch_metrics(pr, hq)
+    assert abs(m["ssim"] - float(g[f"{tag}_ssim"])) < 2e-6          # fp32 window sums in another order than conv2d
+    assert abs(m["mse"] - float(g[f"{tag}_mse"])) <= 1e-6 * float(g[f"{tag}_mse"])
+    assert abs(m["snr"] - float(g[f"{tag}_snr"])) <= 1e-5 * abs(float(g[f"{tag}_snr"]))
+    assert abs(m["pcc"] - float(g[f"{tag}_pcc"])) < 1e-6
+    assert abs(m["psnr"] - float(g[f"{tag}_psnr"])) < 1e-4
+    o, h = OM.rescaled(pr.cpu()).cuda(), OM.rescaled(hq.cpu()).cuda()          # the ssim(img1, img2) entry takes [0,1] images
+    each = ssim(o, h, size_average=False).cpu().numpy()
+    assert np.abs(each - g[f"{tag}_ssim_each"]).max() < 2e-6
+    assert abs(float(SSIM()(o, h)) - float(g[f"{tag}_ssim"])) < 2e-6
+    a, b = M.tile_sums(pr, hq)[0].cpu(), M.tile_sums(pr, hq)[0].cpu()
+    assert torch.equal(a, b)                                                    # deterministic reduction
+
+
+def test_tile_metrics_running_log_and_errors():
+    from hicdiff_amd.Utils import metrics as M
+    from oracle import metrics as OM
+    log = M.MetricLog()
+    tot_mse, n = 0.0, 0
+    for seed, B in ((1, 5), (2, 3)):
+        hq = (rnd(seed, B, 1, 64, 64) * 0.4).clamp(-1, 1)
+        pr = (hq + 0.1 * rnd(seed + 10, B, 1, 64, 64)).clamp(-1, 1)
+        m = log.update(pr.cuda(), hq.cuda())
+        ref = OM.batch_metrics(pr, hq)
+        for k in ("mse", "ssim", "snr", "pcc", "psnr"):
+            assert abs(m[k] - ref[k]) <= 1e-5 * max(1.0, abs(ref[k])), k
+        tot_mse += ref["mse"] * B; n += B
+    assert log.r["nsamples"] == 8 and abs(log.r["mse"] - tot_mse) < 1e-9
+    with pytest.raises(RuntimeError):
+        M.tile_sums(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))              # CPU tensors: no fallback
+    with pytest.raises(ValueError):
+        M.tile_sums(torch.zeros(1, 2, 8, 8).cuda(), torch.zeros(1, 2, 8, 8).cuda())

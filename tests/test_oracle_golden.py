@@ -146,3 +146,20 @@ def test_losses_and_q_sample():
     assert abs(val.item() - g["sr3_l2_loss"].item()) < 1e-5 * abs(val.item())
     ref = OD.DiffusionRef(None, image_size=40, timesteps=1000, beta_schedule="sigmoid")
     assert torch.equal(ref.q_sample(g["x0"], g["q_sample_t"], g["uncond_l2_eps"]), g["q_sample_out"])
+
+
+def test_metrics_oracle_reproduces_reference_ssim_and_batch_values():
+    """oracle/metrics.py against the values the reference's own SSIM module and formulas produced (make_golden.py)."""
+    from oracle import metrics as OM
+    g = np.load(os.path.join(GOLDEN, "metrics.npz"))
+    assert torch.equal(OM.create_window(11, 1), torch.from_numpy(g["window"]))
+    for tag in ("s40", "s64", "far"):
+        pr, hq = torch.from_numpy(g[f"{tag}_pred"]), torch.from_numpy(g[f"{tag}_target"])
+        o, h = OM.rescaled(pr), OM.rescaled(hq)
+        assert abs(float(OM.ssim(o, h)) - float(g[f"{tag}_ssim"])) < 1e-7
+        assert np.abs(OM.ssim(o, h, size_average=False).numpy() - g[f"{tag}_ssim_each"]).max() < 1e-7
+        m = OM.batch_metrics(pr, hq)
+        assert abs(m["mse"] - float(g[f"{tag}_mse"])) <= 1e-6 * float(g[f"{tag}_mse"])
+        assert abs(m["snr"] - float(g[f"{tag}_snr"])) <= 1e-5 * abs(float(g[f"{tag}_snr"]))
+        assert abs(m["pcc"] - float(g[f"{tag}_pcc"])) < 1e-6
+        assert abs(m["psnr"] - float(g[f"{tag}_psnr"])) < 1e-4
