@@ -98,7 +98,8 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
             double eff = (double)B * H * W / ((double)tiles * BM);
             double halo = (double)npx / (double)(tb * th * tw * stride * stride);
             double score = eff - 0.02 * halo;
-            if (score > best_score) { best_score = score; best = {tb, th, tw}; }
+            // ties go to the WIDER tile (tw ascends): a 16-pixel-wide window row keeps the LDS reads conflict-free (decode_row)
+            if (score >= best_score) { best_score = score; best = {tb, th, tw}; }
         }
     }
     cache[key] = best;
