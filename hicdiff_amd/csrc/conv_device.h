@@ -165,7 +165,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (j < nvalid) bias[j] = p.bias[n + j];
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // GroupNorm partial sums of this lane's 4 channels.  Two sets: with two whole 8x8 images per tile (TB == 2, BM == 128)
+    // rows 0..63 belong to sample b0 and rows 64..127 to b0+1, i.e. the upper half of every staging round (lr >= 32).
+    float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool two = p.TB == 2;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
         __syncthreads();                   // operands (tm == 0) / previous round's rows are no longer read
@@ -221,11 +224,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
                     const int pix = rowpix[m];
+                    const bool up = two && lr >= 32;
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
                     if (pix >= 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { s1[j] += o4[j]; s2[j] += o4[j] * o4[j]; }
+                        for (int j = 0; j < 4; ++j) {   // selects, not indexing: a dynamically indexed register array goes to scratch
+                            const float x = o4[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
+                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
+                        }
                         if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
                     }
                 }
@@ -256,13 +263,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
                     const int pix = rowpix[m];
+                    const bool up = two && lr >= 32;
                     const float4 rr = n_rr, sc = n_sc, sh = n_sh, ra = n_ra, rb = n_rb;
                     if (pass + 1 < NPASS) fetch(pass + 1);
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
                     if (pix >= 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] += v[j] * v[j]; }
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = v[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
+                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
+                        }
                     }
                     if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                         if (p.ep & EP_FILM_SILU) {
@@ -294,7 +305,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     for (int j = 0; j < 4; ++j) {
                         if (j >= nvalid) break;
                         float x = v[j];
-                        s1[j] += x; s2[j] += x * x;
+                        s1[0][j] += x; s2[0][j] += x * x;
                         if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                             const int fo = rowb[m] * p.ep_bstride + n + j;
                             x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
@@ -312,18 +323,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         }
     }
     (void)WMN;
-    if (p.gn_part) {   // TB == 1: every row of this workgroup belongs to sample b0
-        __syncthreads();                   // stage is free again: reuse it as [RPP][BN][2]
+    if (p.gn_part) {   // TB == 1: every row of this workgroup belongs to sample b0; TB == 2 (two 8x8 images): a second set
         float* red = stage;
+        for (int h = 0; h < (two ? 2 : 1); ++h) {
+            __syncthreads();               // stage is free again: reuse it as [RPP][BN][2]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { red[(rg * BN + cq * 4 + j) * 2] = s1[j]; red[(rg * BN + cq * 4 + j) * 2 + 1] = s2[j]; }
-        __syncthreads();
-        if (t.tid < BN && t.n0 + t.tid < p.Cout) {
-            float a = 0.f, b = 0.f;
-            for (int g = 0; g < RPP; ++g) { a += red[(g * BN + t.tid) * 2]; b += red[(g * BN + t.tid) * 2 + 1]; }
-            const int slot = t.tile_y * p.tiles_x + t.tile_x;
-            float* d = p.gn_part + (((size_t)t.b0 * p.gn_slots + slot) * p.Cout + t.n0 + t.tid) * 2;
-            d[0] = a; d[1] = b;
+            for (int j = 0; j < 4; ++j) {
+                red[(rg * BN + cq * 4 + j) * 2] = h ? s1[1][j] : s1[0][j];
+                red[(rg * BN + cq * 4 + j) * 2 + 1] = h ? s2[1][j] : s2[0][j];
+            }
+            __syncthreads();
+            if (t.tid < BN && t.n0 + t.tid < p.Cout && t.b0 + h < p.B) {
+                float a = 0.f, b = 0.f;
+                for (int g = 0; g < RPP; ++g) { a += red[(g * BN + t.tid) * 2]; b += red[(g * BN + t.tid) * 2 + 1]; }
+                const int slot = t.tile_y * p.tiles_x + t.tile_x;
+                float* d = p.gn_part + (((size_t)(t.b0 + h) * p.gn_slots + slot) * p.Cout + t.n0 + t.tid) * 2;
+                d[0] = a; d[1] = b;
+            }
         }
     }
 }

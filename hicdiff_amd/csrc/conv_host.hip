@@ -156,9 +156,15 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     return pl;
 }
 
+// The epilogue can produce the GroupNorm partial sums when a tile holds one sample, or exactly two whole 8x8 images in a
+// 128-row tile (sample = upper / lower half of every staging round).
+static bool gn_in_epilogue(const ConvPlan& pl) {
+    return pl.g.TB == 1 || (pl.g.TB == 2 && pl.g.TH * pl.g.TW == 64 && pl.BM == 128);
+}
+
 int conv_gn_slots(const ConvArgs& a) {
     const ConvPlan pl = plan_conv(a);
-    if (pl.g.TB != 1) return 0;
+    if (!gn_in_epilogue(pl)) return 0;
     return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW);
 }
 
@@ -197,7 +203,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.tiles_y = (a.H + g.TH - 1) / g.TH; k.tiles_x = (a.W + g.TW - 1) / g.TW;
     k.ntiles_n = k.CoutPad / pl.BN;
     k.gn_part = nullptr; k.gn_slots = 0;
-    if (a.gn_part && g.TB == 1) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
+    if (a.gn_part && gn_in_epilogue(pl)) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
     L.lds = pl.lds; L.ck = pl.ck; L.cfg = pl.cfg;
     k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
