@@ -20,7 +20,7 @@ struct ConvKArgs {
     const float* ln_stats; const float* ln_g;
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
-    const float* ep_ln_g; unsigned long long w_bstride;
+    const float* ep_ln_g; unsigned long long w_bstride; float* ln_stats_out;
     float* out; float* gn_part; int gn_slots;
     int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
@@ -290,6 +290,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     }
                     const f32x4 o4 = {v[0], v[1], v[2], v[3]};
                     if (pix >= 0 && !(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                    if (p.ep & EP_LN_STATS) {
+                        // statistics of the finished row for the PreNorm of the attention block that consumes it (Cout == BN:
+                        // the row is the CQ consecutive lanes of this pass); same two-pass form as ln_stats_kernel
+                        float sm = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+                        for (int mk = CQ / 2; mk >= 1; mk >>= 1) sm += __shfl_xor(sm, mk, 64);
+                        const float mean = sm * (1.f / BN);
+                        float q = (v[0] - mean) * (v[0] - mean) + (v[1] - mean) * (v[1] - mean) + (v[2] - mean) * (v[2] - mean) + (v[3] - mean) * (v[3] - mean);
+#pragma unroll
+                        for (int mk = CQ / 2; mk >= 1; mk >>= 1) q += __shfl_xor(q, mk, 64);
+                        if (cq == 0 && pix >= 0) { p.ln_stats_out[2 * (size_t)pix] = mean; p.ln_stats_out[2 * (size_t)pix + 1] = 1.f / sqrtf(q * (1.f / BN) + 1e-5f); }
+                    }
                 }
             } else {
                 // narrow outputs (Cout not a multiple of 4: the 1-channel tail of hicedrn): scalar accesses

@@ -179,7 +179,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ln_stats = a.ln_stats; k.ln_g = a.ln_g;
     k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
     k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
-    k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride;
+    k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride; k.ln_stats_out = a.ln_stats_out;
     k.out = a.out;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
@@ -192,6 +192,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     }
     if ((a.in_mode == IN_SOFTMAX32 || a.w_bstride) && !pl.fast) { hd_set_error("conv: the softmax loader / per-sample weights exist in the split-bf16 kernel only"); return -1; }
     if (a.in_mode == IN_SOFTMAX32 && (pl.ck != 32 || a.C1)) { hd_set_error("conv: the softmax loader needs 32-channel slices of one tensor"); return -1; }
+    if ((a.ep & EP_LN_STATS) && (k.Cout != pl.BN || !a.ln_stats_out || !(a.ep & ~EP_LN_STATS))) {
+        hd_set_error("conv: LayerNorm statistics in the epilogue need Cout == tile width and ride on a residual / FiLM epilogue"); return -1;
+    }
     if ((a.ep & EP_LN_RES) && (k.Cout != pl.BN || a.ep != EP_LN_RES || !a.ep_ln_g || !a.res)) {
         hd_set_error("conv: the LayerNorm epilogue needs Cout == tile width (64 or 128), a gain and a residual, and no other epilogue"); return -1;
     }

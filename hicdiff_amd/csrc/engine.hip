@@ -214,7 +214,7 @@ static int load_attn(Loader& L, const std::string& p, int dim, bool linear, Attn
     a->name = p; a->dim = dim; a->linear = linear;
     HD_TRY(L.vec(p + ".fn.norm.g", {1, dim, 1, 1}, &a->norm_g));
     HD_TRY(L.conv(p + ".fn.fn.to_qkv", 384, dim, 1, false, false, false, &a->qkv));
-    if (linear && dim == 64) {
+    if (linear && (dim == 64 || dim == 128 || dim == 256)) {
         // fused key/value side (linattn_fused.hip): q-only projection + packed k/v weights
         const hd_named_tensor* t = L.get(p + ".fn.fn.to_qkv.weight", {384, dim, 1, 1});
         if (!t) return HD_ENOWEIGHT;
@@ -391,7 +391,9 @@ static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* 
 }
 
 // ResnetBlock (src/hicdiff.py:185-197; SR3: src/hicdiff_sr3.py:246-251).  in1 != null: channel concat.
-static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, Act* out) {
+// stats (optional): [pixels][2] buffer for the channel-LayerNorm statistics of the block's output, for the attention block
+// that consumes it; *stats_done is set when the block's tail produced them (C = 64 / 128 [/ 256 with identity shortcut]).
+static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, Act* out, float* stats = nullptr, bool* stats_done = nullptr) {
     const int H = in0.H, W = in0.W, C = w.cout;
     const bool sr3 = r.c->arch.sr3;
     Act h1, h2;
@@ -414,20 +416,29 @@ static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, 
         s.in0 = in0.p; s.C0 = in0.C; s.in1 = in1 ? in1->p : nullptr; s.C1 = in1 ? in1->C : 0;
         s.B = r.B; s.H = H; s.W = W; s.IH = H; s.IW = W; s.stride = 1; s.pad = 0; s.cw = w.res; s.out = out->p;
         s.ep = EP_RES_AFFINE_SILU; s.res = h2.p; s.resA = A2; s.resB = B2; s.res_bstride = C;
+        if (stats && !r.dry && r.c->precision == HD_PREC_BF16X3 && (C == 64 || C == 128)) {   // tile width == C there
+            s.ep |= EP_LN_STATS; s.ln_stats_out = stats;
+            if (stats_done) *stats_done = true;
+        }
         HD_TRY(run_conv(r, s));
     } else if (!r.dry) {
-        HD_TRY(launch_affine_silu_add(h2.p, A2, B2, in0.p, out->p, r.B, H * W, C, r.st));
+        // (the exact-fp32 arithmetic keeps its separately validated ln_stats pass: DDIM amplifies 1e-7 reorderings to 1e-3)
+        const int rc = launch_affine_silu_add(h2.p, A2, B2, in0.p, out->p, r.B, H * W, C, r.st, r.c->precision == HD_PREC_BF16X3 ? stats : nullptr);
+        if (rc < 0) return keep_err(r.c, rc);
+        if (rc == 1 && stats_done) *stats_done = true;
     }
     r.free(h2); r.free(A2); r.free(B2);
     return 0;
 }
 
 // Residual(PreNorm(LinearAttention)) / Residual(PreNorm(Attention)), src/hicdiff.py:199-251.
-static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out) {
+// stats_in: the PreNorm statistics of x when the producing block already wrote them (ownership passes to this call).
+static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float* stats_in = nullptr, bool stats_ready = false) {
     const int H = x.H, W = x.W, C = x.C, HW = H * W, heads = 4;
     const size_t P = x.pixels();
-    float* stats; HD_TRY(r.alloc(P * 2, &stats));
-    if (!r.dry) HD_TRY(launch_ln_stats(x.p, P, C, stats, r.st));
+    float* stats = stats_in;
+    if (!stats) HD_TRY(r.alloc(P * 2, &stats));
+    if (!r.dry && !stats_ready) HD_TRY(launch_ln_stats(x.p, P, C, stats, r.st));
     const bool fused = w.linear && w.fused && r.c->precision == HD_PREC_BF16X3;
     // the dry run sizes the workspace for either arithmetic mode (hd_set_precision may switch later)
     Act qkv; HD_TRY(r.act(H, W, (fused && !r.dry) ? 128 : 384, &qkv));
@@ -533,8 +544,10 @@ static int unet_forward(Run& r, const float* x, const float* cond, float* eps) {
         if (cur.p != h0.p) r.free(cur);
         skips.push_back(a1);
         HD_TRY(probe(r, "downs." + std::to_string(i) + ".0", a1));
-        HD_TRY(unet_resblock(r, s.r2, a1, nullptr, &a2));
-        HD_TRY(unet_attention(r, s.attn, a2, &a3));
+        float* st; bool st_done = false;
+        HD_TRY(r.alloc(a1.pixels() * 2, &st));
+        HD_TRY(unet_resblock(r, s.r2, a1, nullptr, &a2, st, &st_done));
+        HD_TRY(unet_attention(r, s.attn, a2, &a3, st, st_done));
         HD_TRY(probe(r, "downs." + std::to_string(i) + ".2", a3));
         r.free(a2);
         skips.push_back(a3);
@@ -563,8 +576,10 @@ static int unet_forward(Run& r, const float* x, const float* cond, float* eps) {
         Act sk = skips.back(); skips.pop_back();
         HD_TRY(unet_resblock(r, s.r1, cur, &sk, &a1)); r.free(cur); r.free(sk);
         sk = skips.back(); skips.pop_back();
-        HD_TRY(unet_resblock(r, s.r2, a1, &sk, &a2)); r.free(a1); r.free(sk);
-        HD_TRY(unet_attention(r, s.attn, a2, &a3)); r.free(a2);
+        float* st; bool st_done = false;
+        HD_TRY(r.alloc(a1.pixels() * 2, &st));
+        HD_TRY(unet_resblock(r, s.r2, a1, &sk, &a2, st, &st_done)); r.free(a1); r.free(sk);
+        HD_TRY(unet_attention(r, s.attn, a2, &a3, st, st_done)); r.free(a2);
         ConvArgs k;
         k.in0 = a3.p; k.C0 = a3.C; k.B = r.B; k.IH = a3.H; k.IW = a3.W; k.cw = s.resample; k.stride = 1; k.pad = 1;
         if (s.last) { k.H = a3.H; k.W = a3.W; } else { k.H = a3.H * 2; k.W = a3.W * 2; k.upsample = 1; }

@@ -35,6 +35,7 @@ enum EpFlags {
     EP_ADD_SILU = 2,       // v = silu(v + shift[b][n])                            (hicedrn SR3 block)
     EP_RES = 4,            // v = alpha * v + res[pix][n]
     EP_RES_AFFINE_SILU = 8, // v = v + silu(res[pix][n] * resA[b][n] + resB[b][n]) (UNet block tail through res_conv)
+    EP_LN_STATS = 32,      // also write the channel-LayerNorm statistics (mean, rstd) of the final row to ln_stats_out[pix]; needs Cout == tile width
     EP_LN_RES = 16         // v = LayerNorm_channels(v) * ep_ln_g[n] + res[pix][n]   (LinearAttention to_out tail, src/hicdiff.py:207-210,64-70); needs Cout == tile width
 };
 
@@ -58,6 +59,7 @@ struct ConvArgs {
     float alpha = 1.f;
     const float* res = nullptr; const float* resA = nullptr; const float* resB = nullptr; int res_bstride = 0;
     const float* ep_ln_g = nullptr;   // EP_LN_RES: LayerNorm gain [Cout]
+    float* ln_stats_out = nullptr;    // EP_LN_STATS: [pixels][2]
     size_t w_bstride = 0;             // bf16x3 only: bytes between per-sample images of cw.wsplit (0: one shared weight); forces one sample per tile
     float* out = nullptr;
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
@@ -102,8 +104,8 @@ int launch_gn_partial(const float* x, int B, int HW, int C, float* part, int* sl
 int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma,
                        const float* beta, const float* film, int film_bstride, int film_off, int film_mode,
                        float* A, float* Bv, float* E, hipStream_t st);
-int launch_affine_silu_add(const float* h, const float* A, const float* Bv, const float* res, float* out,
-                           int B, int HW, int C, hipStream_t st);
+int launch_affine_silu_add(const float* h, const float* A, const float* Bv, const float* res, float* out, int B, int HW, int C,
+                           hipStream_t st, float* stats = nullptr);   // stats: see small_kernels.hip; returns 1 when it wrote them
 int launch_ln_stats(const float* x, size_t P, int C, float* stats, hipStream_t st);
 int launch_ln_residual(const float* y, const float* g, const float* res, float* out, size_t P, int C, hipStream_t st);
 size_t linattn_scratch_floats(int B, int HW, int heads);

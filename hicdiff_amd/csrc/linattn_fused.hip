@@ -1,4 +1,4 @@
-// Fused key/value side of LinearAttention (src/hicdiff.py:212-223) for 64-channel feature maps:
+// Fused key/value side of LinearAttention (src/hicdiff.py:212-223) for 64-, 128- and 256-channel feature maps:
 //
 //   LN(x) -> k, v = to_qkv[128:384](LN(x)) -> softmax_n(k) -> context[d][e] = sum_n softmax(k)[d][n] v[e][n] / HW
 //
@@ -214,9 +214,12 @@ int linattn_kv_nsplit(int HW) { return (HW + KV_TOK - 1) / KV_TOK; }
 
 int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
                             hipStream_t st) {
-    if (C != 64) { hd_set_error("linattn_kv_fused: only 64-channel maps"); return -1; }
     const int nsplit = linattn_kv_nsplit(HW);
-    hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, dim3((unsigned)(B * nsplit)), dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    const dim3 grid((unsigned)(B * nsplit));
+    if (C == 64) hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    else if (C == 128) hipLaunchKernelGGL(linattn_kv_fused_kernel<128>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    else if (C == 256) hipLaunchKernelGGL(linattn_kv_fused_kernel<256>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    else { hd_set_error("linattn_kv_fused: 64-, 128- and 256-channel maps only"); return -1; }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hd_set_error(std::string("linattn_kv_fused: ") + hipGetErrorString(e)); return -3; }
     return 0;

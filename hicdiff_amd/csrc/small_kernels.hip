@@ -272,11 +272,46 @@ __global__ __launch_bounds__(256) void affine_silu_add_kernel(const float* __res
     }
 }
 
+// The same tail that also leaves the per-pixel channel LayerNorm statistics (mean, rstd) of its OUTPUT for the attention
+// block that follows (PreNorm, src/hicdiff.py:99-118): a pixel's C/4 float4 lanes are consecutive lanes of one wave.
+template <int C4>
+__global__ __launch_bounds__(256) void affine_silu_add_stats_kernel(const float* __restrict__ h, const float* __restrict__ A,
+                                                                    const float* __restrict__ Bv, const float* __restrict__ res,
+                                                                    float* __restrict__ out, float* __restrict__ stats, size_t n4, int HWC4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {   // n4 is a multiple of 256 / of C4
+        const int b = (int)(i / HWC4), c4 = (int)(i % C4);
+        float4 v = reinterpret_cast<const float4*>(h)[i];
+        const float4 a = reinterpret_cast<const float4*>(A)[b * C4 + c4];
+        const float4 bb = reinterpret_cast<const float4*>(Bv)[b * C4 + c4];
+        const float4 r = reinterpret_cast<const float4*>(res)[i];
+        v.x = silu_f(v.x * a.x + bb.x) + r.x; v.y = silu_f(v.y * a.y + bb.y) + r.y;
+        v.z = silu_f(v.z * a.z + bb.z) + r.z; v.w = silu_f(v.w * a.w + bb.w) + r.w;
+        reinterpret_cast<float4*>(out)[i] = v;
+        float s = v.x + v.y + v.z + v.w;
+#pragma unroll
+        for (int m = C4 / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float mean = s / (4 * C4);
+        const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+        float q = dx * dx + dy * dy + dz * dz + dw * dw;
+#pragma unroll
+        for (int m = C4 / 2; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+        if (c4 == 0) { const size_t px = i / C4; stats[2 * px] = mean; stats[2 * px + 1] = 1.f / sqrtf(q / (4 * C4) + 1e-5f); }
+    }
+}
+
+// stats != nullptr: also write the LayerNorm statistics of the output (C = 64, 128 or 256 and B*HW*C/4 a multiple of 256:
+// returns 1 when it did, 0 when the caller still has to run ln_stats; negative on error)
 int launch_affine_silu_add(const float* h, const float* A, const float* Bv, const float* res, float* out, int B, int HW, int C,
-                           hipStream_t st) {
+                           hipStream_t st, float* stats) {
     const size_t n4 = (size_t)B * HW * C / 4;
     unsigned grid = (unsigned)((n4 + 255) / 256);
     if (grid > 16384) grid = 16384;
+    if (stats && n4 % 256 == 0 && (C == 64 || C == 128 || C == 256)) {
+        if (C == 64) hipLaunchKernelGGL(affine_silu_add_stats_kernel<16>, dim3(grid), dim3(256), 0, st, h, A, Bv, res, out, stats, n4, HW * C / 4);
+        else if (C == 128) hipLaunchKernelGGL(affine_silu_add_stats_kernel<32>, dim3(grid), dim3(256), 0, st, h, A, Bv, res, out, stats, n4, HW * C / 4);
+        else hipLaunchKernelGGL(affine_silu_add_stats_kernel<64>, dim3(grid), dim3(256), 0, st, h, A, Bv, res, out, stats, n4, HW * C / 4);
+        return check_launch("affine_silu_add_stats") == 0 ? 1 : -3;
+    }
     hipLaunchKernelGGL(affine_silu_add_kernel, dim3(grid), dim3(256), 0, st, h, A, Bv, res, out, n4, HW * C / 4, C / 4);
     return check_launch("affine_silu_add");
 }
