@@ -696,10 +696,10 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
 
 void hd_destroy(hd_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    for (void* p : c->owned) hipFree(p);
-    if (c->pool.base) hipFree(c->pool.base);
-    if (c->eps_buf) hipFree(c->eps_buf);
+    (void)hipSetDevice(c->device);
+    for (void* p : c->owned) (void)hipFree(p);
+    if (c->pool.base) (void)hipFree(c->pool.base);
+    if (c->eps_buf) (void)hipFree(c->eps_buf);
     for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (c->sp_dev) (void)hipFree(c->sp_dev);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
@@ -738,7 +738,7 @@ int hd_reserve(hd_ctx* c, int B, int S) {
         if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
         for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         c->graphs.clear();                       // captured addresses die with the old block
-        if (c->pool.base) hipFree(c->pool.base);
+        if (c->pool.base) (void)hipFree(c->pool.base);
         c->pool.base = nullptr; c->pool.cap = 0;
         void* p = nullptr;
         if (hipMalloc(&p, need) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(workspace) failed");
@@ -749,7 +749,7 @@ int hd_reserve(hd_ctx* c, int B, int S) {
         if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
         for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         c->graphs.clear();
-        if (c->eps_buf) hipFree(c->eps_buf);
+        if (c->eps_buf) (void)hipFree(c->eps_buf);
         void* p = nullptr;
         if (hipMalloc(&p, en * sizeof(float)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(eps) failed");
         c->eps_buf = (float*)p; c->eps_cap = en;
