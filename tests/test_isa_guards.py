@@ -1,0 +1,52 @@
+"""Build-time guards on the generated gfx950 code of the convolution kernels (no GPU needed: hipcc cross-compiles).
+
+1. No scratch: register arrays that hipcc cannot keep in registers silently go to scratch memory and cost 2-3x.
+2. No packed fp32 instruction in the split-bf16 conv kernels broadcasts BOTH lanes of an operand from the odd register
+   of a pair (``op_sel:[0,1]`` / ``[1,0]`` on a two-source op, ``op_sel:[0,1,0]``-style on v_pk_fma).  Every build of the
+   LayerNorm loader that did produced exact-zero lanes on large grids; the kernel avoids the
+   pattern by copying the statistics out of their load pair, and this test keeps it that way.
+"""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "hicdiff_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _asm(src):
+    out = os.path.join(tempfile.mkdtemp(prefix="hd_isa_"), os.path.basename(src) + ".s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only",
+           os.path.join(CSRC, src), "-o", out]
+    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    with open(out) as f:
+        text = f.read()
+    shutil.rmtree(os.path.dirname(out), ignore_errors=True)
+    return text
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", ["conv_bf16x3_ck16.hip", "conv_bf16x3_ck32.hip"])
+def test_conv_kernels_have_no_scratch_and_no_odd_register_broadcast(src):
+    text = _asm(src)
+    kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
+    assert len(kernels) >= 20
+    for name, body in kernels:
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
+        assert m and int(m.group(1)) == 0, f"{name} uses {m.group(1) if m else '?'} bytes of scratch per lane"
+    bad = []
+    for line in text.splitlines():
+        line = line.strip()
+        if not line.startswith("v_pk_") or "_f32" not in line.split()[0] or "op_sel:" not in line:
+            continue
+        sel = [int(x) for x in re.search(r"op_sel:\[([0-9,]+)\]", line).group(1).split(",")]
+        hi = re.search(r"op_sel_hi:\[([0-9,]+)\]", line)
+        sel_hi = [int(x) for x in hi.group(1).split(",")] if hi else [1] * len(sel)
+        if any(a == 1 and b == 1 for a, b in zip(sel, sel_hi)):      # lane 0 AND lane 1 of that operand read the odd register
+            bad.append(line)
+    assert not bad, "packed fp32 ops broadcasting from the odd register of a pair:\n" + "\n".join(bad[:8])
