@@ -82,6 +82,7 @@ struct AttnW {
     ConvW qkv, out;
     ConvW qonly;                       // fused path: q = to_qkv[0:128] only
     unsigned short* wkv = nullptr;     // fused path: split k/v weight image with the LayerNorm gain folded in
+    unsigned short* wq = nullptr;      // chained q path (dim 64): split q weight image with the LayerNorm gain folded in
     bool fused = false;
     int dim = 0; bool linear = true;
     std::string name;
@@ -227,6 +228,10 @@ static int load_attn(Loader& L, const std::string& p, int dim, bool linear, Attn
         HD_TRY(launch_split_conv(q.w, q.wsplit, 1, dim, 128, q.ck, L.st));
         if (!a->wkv) { a->wkv = (unsigned short*)L.dev((size_t)256 * dim); if (!a->wkv) return HD_EHIP; }
         HD_TRY(launch_pack_kv((const float*)t->data, a->norm_g, dim, a->wkv, L.st));
+        if (dim == 64) {
+            if (!a->wq) { a->wq = (unsigned short*)L.dev((size_t)128 * dim); if (!a->wq) return HD_EHIP; }   // 128*dim*2 shorts
+            HD_TRY(launch_pack_q((const float*)t->data, a->norm_g, dim, a->wq, L.st));
+        }
         a->fused = true;
     }
     if (linear) {
@@ -440,20 +445,26 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
     if (!stats) HD_TRY(r.alloc(P * 2, &stats));
     if (!r.dry && !stats_ready) HD_TRY(launch_ln_stats(x.p, P, C, stats, r.st));
     const bool fused = w.linear && w.fused && r.c->precision == HD_PREC_BF16X3;
+    // chained q side (linattn_q_fused.hip): 64-channel maps of >= 256 pixels -- q, the attention output and the
+    // pre-LayerNorm tensor never exist; the kernel reads x and the statistics and writes the block's output
+    const bool qchain = fused && C == 64 && HW >= 256 && w.wq && w.out.CoutPad == 64 && !r.dry;
     // the dry run sizes the workspace for either arithmetic mode (hd_set_precision may switch later)
-    Act qkv; HD_TRY(r.act(H, W, (fused && !r.dry) ? 128 : 384, &qkv));
-    ConvArgs q;
-    q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = fused ? w.qonly : w.qkv; q.out = qkv.p;
-    q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
-    HD_TRY(run_conv(r, q));
-    r.free(stats);
+    Act qkv{};
+    if (!qchain) {
+        HD_TRY(r.act(H, W, (fused && !r.dry) ? 128 : 384, &qkv));
+        ConvArgs q;
+        q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = fused ? w.qonly : w.qkv; q.out = qkv.p;
+        q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
+        HD_TRY(run_conv(r, q));
+        r.free(stats); stats = nullptr;
+    }
     // q side, fused form (split-bf16 arithmetic, feature maps of >= 256 pixels so a conv tile never mixes samples):
     // the context is folded into to_out's weight per sample and the q-softmax runs in to_out's loader, so neither the
     // attention output nor (for C = 64 / 128, where a tile holds whole channel rows) the pre-LayerNorm tensor exists.
     const bool qfuse = fused && HW >= 256 && w.out.ck == 32;
     const bool lnfuse = qfuse && (C == 64 || C == 128);
     Act att{};
-    if (!qfuse || r.dry) HD_TRY(r.act(H, W, 128, &att));
+    if ((!qfuse && !qchain) || r.dry) HD_TRY(r.act(H, W, 128, &att));
     unsigned short* wfold = nullptr;
     const size_t wfold_bytes = (size_t)heads * w.out.CoutPad * 64 * sizeof(unsigned short);   // per sample
     if (fused) {
@@ -462,12 +473,12 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
         float *ctx, *scr;
         HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
         HD_TRY(r.alloc(std::max(slots * (32 + 32 + 32 * 32), linattn_scratch_floats(r.B, HW, heads)), &scr));
-        if (qfuse || r.dry) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
+        if (qfuse || qchain || r.dry) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
         if (!r.dry) {
             float* pmax = scr; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
             HD_TRY(launch_linattn_kv_fused(x.p, w.wkv, r.B, HW, C, pmax, psum, pctx, r.st));
             HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nsplit, HW, ctx, r.st));
-            if (qfuse) HD_TRY(launch_linattn_fold_out(w.out.w, ctx, r.B, w.out.CoutPad, wfold, r.st));
+            if (qfuse || qchain) HD_TRY(launch_linattn_fold_out(w.out.w, ctx, r.B, w.out.CoutPad, wfold, r.st, qchain ? 1 : 0));
             else HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st));
         }
         r.free(ctx); r.free(scr);
@@ -481,6 +492,14 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
         r.free(ctx); r.free(scr);
     } else if (!r.dry) {
         HD_TRY(launch_attn_full(qkv.p, r.B, HW, heads, att.p, r.st));
+    }
+    if (qchain) {
+        HD_TRY(r.act(H, W, C, out));
+        HD_TRY(launch_linattn_q_fused(x.p, stats, w.wq, wfold, w.out.bias, w.out_g, out->p, r.B, HW, C, r.st));
+        r.free(stats);
+        if (wfold) r.free((float*)wfold);
+        if (att.p) r.free(att);
+        return 0;
     }
     if (!qfuse) r.free(qkv);
     HD_TRY(r.act(H, W, C, out));
@@ -913,6 +932,25 @@ int hd_debug_linattn_out(const float* q, const float* ctx, const float* wout, co
     }
     (void)hipStreamSynchronize(st);
     (void)hipFree(pw); (void)hipFree(pf); if (py) (void)hipFree(py);
+    return rc;
+}
+
+int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, const float* ctx, const float* wout, const float* bias,
+                       const float* gout, int B, int H, int W, float* out, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int C = 64;
+    if (!x || !norm_g || !wqkv || !ctx || !wout || !gout || !out) return HD_EINVAL;
+    const size_t P = (size_t)B * H * W;
+    void *pw = nullptr, *pf = nullptr, *pq = nullptr, *ps = nullptr;
+    if (hipMalloc(&pw, (size_t)128 * C * sizeof(float)) != hipSuccess || hipMalloc(&pf, (size_t)B * 4 * C * 64 * sizeof(unsigned short)) != hipSuccess ||
+        hipMalloc(&pq, (size_t)128 * C * 2 * sizeof(unsigned short)) != hipSuccess || hipMalloc(&ps, P * 2 * sizeof(float)) != hipSuccess) return HD_EHIP;
+    int rc = launch_pack_conv(wout, (float*)pw, C, 128, 1, 1, C, 0, 0, st);
+    if (rc == 0) rc = launch_linattn_fold_out((const float*)pw, ctx, B, C, (unsigned short*)pf, st, 1);
+    if (rc == 0) rc = launch_pack_q(wqkv, norm_g, C, (unsigned short*)pq, st);
+    if (rc == 0) rc = launch_ln_stats(x, P, C, (float*)ps, st);
+    if (rc == 0) rc = launch_linattn_q_fused(x, (const float*)ps, (const unsigned short*)pq, (const unsigned short*)pf, bias, gout, out, B, H * W, C, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(pw); (void)hipFree(pf); (void)hipFree(pq); (void)hipFree(ps);
     return rc;
 }
 

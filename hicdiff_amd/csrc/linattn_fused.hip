@@ -231,7 +231,7 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
 // (src/hicdiff.py:217-226).  This kernel writes W'_b in the split-bf16 slab layout of the conv kernel
 // ([slice = head][CoutPad][32 hi | 32 lo]); the conv's loader then applies the softmax (IN_SOFTMAX32).
 __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __restrict__ wout, const float* __restrict__ ctx, int CoutPad,
-                                                               unsigned short* __restrict__ dst) {
+                                                               unsigned short* __restrict__ dst, int permute) {
     constexpr int D = 32;
     __shared__ float cs[D][D + 1];
     const int bh = blockIdx.x, h = bh & 3, tid = threadIdx.x;       // heads = 4
@@ -247,13 +247,16 @@ __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __re
         acc *= 0.17677669529663687f;                                 // dim_head ** -0.5
         const __bf16 hi = (__bf16)acc;
         const __bf16 lo = (__bf16)(acc - (float)hi);
-        out[(size_t)o * 2 * D + d] = __builtin_bit_cast(unsigned short, hi);
-        out[(size_t)o * 2 * D + D + d] = __builtin_bit_cast(unsigned short, lo);
+        // permute: d axis in the order an MFMA accumulator presents it as an operand (linattn_q_fused.hip):
+        // position 16*s + 8*half + 4*g + i  <-  d = 16*s + 8*g + 4*half + i
+        const int pos = permute ? (d & 16) | ((d & 4) << 1) | ((d & 8) >> 1) | (d & 3) : d;
+        out[(size_t)o * 2 * D + pos] = __builtin_bit_cast(unsigned short, hi);
+        out[(size_t)o * 2 * D + D + pos] = __builtin_bit_cast(unsigned short, lo);
     }
 }
 
-int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st) {
-    hipLaunchKernelGGL(linattn_fold_out_kernel, dim3(B * 4), dim3(256), 0, st, wout_packed, ctx, CoutPad, dst);
+int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st, int permute) {
+    hipLaunchKernelGGL(linattn_fold_out_kernel, dim3(B * 4), dim3(256), 0, st, wout_packed, ctx, CoutPad, dst, permute);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hd_set_error(std::string("linattn_fold_out launch: ") + hipGetErrorString(e)); return -3; }
     return 0;

@@ -27,6 +27,12 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
 int hd_debug_linattn_out(const float* q, const float* ctx, const float* wout, const float* bias, const float* g, const float* res,
                          int B, int H, int W, int C, float* out, void* stream);
 
+/* The chained q side for 64-channel maps (linattn_q_fused.hip): out = LayerNorm(to_out(einsum(context,
+ * softmax_d(to_q(LayerNorm(x) * norm_g)) * scale))) * gout + x in one kernel.  x, out: NHWC [B,H,W,64];
+ * wqkv: torch layout [384,64,1,1] (rows 0..127 are q); ctx: [B,4,32,32]; wout: [64,128,1,1]. */
+int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, const float* ctx, const float* wout, const float* bias,
+                       const float* gout, int B, int H, int W, float* out, void* stream);
+
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.

@@ -221,3 +221,43 @@ def test_tile_metrics_running_log_and_errors():
         M.tile_sums(torch.zeros(1, 1, 8, 8), torch.zeros(1, 1, 8, 8))              # CPU tensors: no fallback
     with pytest.raises(ValueError):
         M.tile_sums(torch.zeros(1, 2, 8, 8).cuda(), torch.zeros(1, 2, 8, 8).cuda())
+
+
+@pytest.mark.parametrize("B,S", [(2, 16), (3, 24), (32, 64)])
+def test_linear_attention_q_chain_fused(B, S):
+    """PreNorm -> to_q -> softmax_d -> context -> to_out -> LayerNorm -> + x in ONE kernel (64-channel maps) against the
+    reference formulation (src/hicdiff.py:99-118, 212-226, 64-70); the large case also has to repeat bit-for-bit."""
+    lib = _lib()
+    lib.hd_debug_linattn_q.restype = C.c_int
+    lib.hd_debug_linattn_q.argtypes = [C.c_void_p] * 7 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p]
+    heads, D, Cc = 4, 32, 64
+    x = rnd(1, B, Cc, S, S) * 1.5 + 0.3
+    ng = rnd(2, Cc) * 0.2 + 1
+    wqkv = rnd(3, 3 * heads * D, Cc, 1, 1) / 6
+    ctx = rnd(4, B, heads, D, D) * 0.3
+    wout, bias, g = rnd(5, Cc, heads * D, 1, 1) / 11, rnd(6, Cc) * 0.1, rnd(7, Cc) * 0.2 + 1
+    mean, var = x.mean(dim=1, keepdim=True), x.var(dim=1, unbiased=False, keepdim=True)
+    xn = (x - mean) * (var + 1e-5).rsqrt() * ng.view(1, -1, 1, 1)
+    q = F.conv2d(xn, wqkv[: heads * D])
+    qs = q.view(B, heads, D, S * S).softmax(dim=-2) * D ** -0.5
+    o = torch.einsum("bhde,bhdn->bhen", ctx, qs).reshape(B, heads * D, S, S)
+    y = F.conv2d(o, wout, bias)
+    m2, v2 = y.mean(dim=1, keepdim=True), y.var(dim=1, unbiased=False, keepdim=True)
+    ref = (y - m2) * (v2 + 1e-5).rsqrt() * g.view(1, -1, 1, 1) + x
+
+    def run():
+        dev = "cuda"
+        t = lambda a: a.to(dev).contiguous()
+        xd, ngd, wqd, cd, wd, bd, gd = t(nhwc(x)), t(ng), t(wqkv), t(ctx), t(wout), t(bias), t(g)
+        out = torch.full((B, S, S, Cc), float("nan"), device=dev)
+        p = lambda a: C.c_void_p(a.data_ptr())
+        rc = lib.hd_debug_linattn_q(p(xd), p(ngd), p(wqd), p(cd), p(wd), p(bd), p(gd), B, S, S, p(out),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        return out.permute(0, 3, 1, 2).cpu()
+
+    outs = [run() for _ in range(3 if B >= 32 else 1)]
+    assert rel_err(ref, outs[0]) < 1e-4
+    for o2 in outs[1:]:
+        assert torch.equal(outs[0], o2)
