@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __re
     const float* w = wout + (size_t)h * D * CoutPad;                 // packed fp32 [Cin = 128][CoutPad]
     unsigned short* out = dst + (size_t)bh * CoutPad * 2 * D;        // [b][head][CoutPad][64]
     for (int i = tid; i < CoutPad * D; i += 256) {
-        const int o = i % CoutPad, d = i / CoutPad;
+        const int d = i % D, o = i / D;          // d fastest: the 32 lanes of an output row write 64 contiguous bytes
         float acc = 0.f;
 #pragma unroll
         for (int e = 0; e < D; ++e) acc += w[(size_t)e * CoutPad + o] * cs[d][e];

@@ -8,8 +8,8 @@
 //     (W'_b = scale * Wout . ctx_b, split-bf16 slabs [head][64 rows][32 hi | 32 lo]);
 //   * to_q's weight comes with the PreNorm gain folded in, split the same way ([C/32 slices][128 rows][32 hi | 32 lo]);
 //   * the PreNorm statistics (mean, rstd per pixel) come from the block that produced x.
-// One workgroup of 8 waves per 256 pixels of one sample; a wave owns 32 pixels end to end, so after the one barrier
-// that publishes the two weight images no wave waits for another:
+// One workgroup of 8 waves per 256 pixels of one sample (two workgroups per CU); a wave owns 32 pixels end to end, so
+// between the barrier that publishes the two weight images and the one before the epilogue no wave waits for another:
 //   x row -> LayerNorm -> split-bf16 A fragments in REGISTERS (each lane loads the 8 channels its fragment needs);
 //   per head: q_h^T = Wq_h . A^T (12 MFMAs; the transposed product puts the head's 32 channels on the REGISTER index, so
 //   the softmax is an in-lane reduction plus one exchange with lane ^ 32), p goes from the accumulator registers straight
@@ -29,7 +29,8 @@ constexpr int QF_PITCH = 144;                 // one 32-channel split row: 32 bf
 constexpr int QF_WQ_BYTES = 2 * 128 * QF_PITCH;   // [2 slices][128 q rows]
 constexpr int QF_WF_BYTES = 4 * 64 * QF_PITCH;    // [4 heads][64 output rows]
 constexpr int QF_STAGE = 32 * 68 * 4;             // per wave: epilogue staging [32 px][64 + 4] floats
-constexpr int QF_LDS = QF_WQ_BYTES + QF_WF_BYTES + 8 * QF_STAGE;
+static_assert(8 * QF_STAGE <= QF_WQ_BYTES + QF_WF_BYTES, "the epilogue staging overlays the two weight images");
+constexpr int QF_LDS = QF_WQ_BYTES + QF_WF_BYTES;   // 73,728 B: two workgroups (16 waves) per CU
 
 template <int CTRL>
 __device__ __forceinline__ float dppf(float x) {
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(512) void linattn_q_fused_kernel(const float* __res
     char* WQs = qf_lds;
     char* WFs = WQs + QF_WQ_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
-    char* stg = WFs + QF_WF_BYTES + w * QF_STAGE;
+    char* stg = qf_lds + w * QF_STAGE;                  // epilogue staging: overlays the weight images once every wave is done with them
     const int b = blockIdx.x / tiles_per_sample, tile = blockIdx.x % tiles_per_sample;
     const int n0 = tile * 256 + w * 32;                 // first pixel of this wave inside the sample
 
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(512) void linattn_q_fused_kernel(const float* __res
     }
 
     // ---- epilogue through the wave's stage [32 px][68 floats]: rows become contiguous, 16 lanes per row
+    __syncthreads();                      // the stage overlays the weight images: every wave has left the head loop
     float* sf = reinterpret_cast<float*>(stg);
 #pragma unroll
     for (int tn = 0; tn < 2; ++tn)
