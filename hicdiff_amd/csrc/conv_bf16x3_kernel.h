@@ -12,7 +12,8 @@
 // are split on the fly while the loader applies its transform.
 //
 // Pipeline.  One iteration per (K slice c, filter tap), ONE barrier each.  After the barrier, in program order:
-//   1. weight slab it+1: prefetch registers -> the LDS buffer slab it-1 was read from; slab it+2 is requested;
+//   1. weight slab it+1: prefetch registers -> the LDS buffer slab it-1 was read from; a later slab is requested into the
+//      registers just freed (3x3 kernels keep three register sets in flight: slab it+4; the any-filter kernels one: slab it+2);
 //   2. this tap's share of the raw fp32 values of slice c+1 is requested (registers xr);
 //   3. the MFMA cluster of iteration it.
 // Everything in 1 and 2 is asynchronous, so its latency sits behind the MFMAs instead of in front of a
@@ -22,6 +23,8 @@
 // kernel then runs at the SUM of its load, staging and MFMA times).
 // The per-slice operands of the loader transform (GroupNorm/FiLM scale and shift, LayerNorm gain) come from
 // a small double-buffered LDS table filled one slice ahead, so staging a slice touches no global memory.
+// Loader transforms: none, GroupNorm-apply + FiLM + SiLU (+ additive term), channel LayerNorm, softmax over each
+// 32-channel head (LinearAttention's q); weights may be per sample (one sample per tile).
 // 8-wave variant (one workgroup per CU): the activation window is double-buffered and slice c+1 is
 // transformed/split/written item by item during the taps of slice c; 4-wave variants (two workgroups per
 // CU, which overlap each other) keep one window and stage between two barriers at the slice switch.
