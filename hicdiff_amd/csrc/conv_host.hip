@@ -116,7 +116,11 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     ConvPlan pl{};
     pl.fast = a.precision == HD_PREC_BF16X3 && a.cw.wsplit != nullptr;
     pl.ck = pl.fast ? a.cw.ck : 16;
-    const bool wide = a.cw.CoutPad % 128 == 0;
+    // Feature maps smaller than 8x8 (the 5x5 level of 40x40 tiles) take 64-wide N tiles even for wide outputs: a handful of
+    // M tiles with K in the thousands needs more workgroups, not bigger ones (unet40, 64 tiles: 4.54 -> 3.73 ms/step; measured
+    // a loss from 8x8 upwards at 256 tiles).  By the map size only -- never by the batch.
+    static const int narrow_max_hw = getenv("HICDIFF_NARROW_MAXHW") ? atoi(getenv("HICDIFF_NARROW_MAXHW")) : 63;
+    const bool wide = a.cw.CoutPad % 128 == 0 && a.H * a.W > narrow_max_hw;
     pl.BN = wide ? 128 : 64;
     pl.BM = 128; pl.WM = 2; pl.cfg = wide ? 0 : 1;
     // 256 x 64 tile (waves 4 x 1) for 64-channel outputs on large feature maps.  The choice must not depend on
