@@ -888,6 +888,20 @@ int hd_tile_metrics(const float* pred, const float* target, int B, int S, int re
     return launch_tile_metrics(pred, target, B, S, rescale, partial, sums, ssim_each, (hipStream_t)stream) == 0 ? HD_OK : HD_EINVAL;
 }
 
+int hd_split_pieces(const float* mat, int n, const int* origins, int ntiles, int piece, float* tiles, void* stream) {
+    if (n < 0 || ntiles < 0 || piece < 1) return HD_EINVAL;
+    if (ntiles == 0) return HD_OK;
+    if (!mat || !origins || !tiles || n < 1) return HD_EINVAL;
+    return launch_split_pieces(mat, n, origins, ntiles, piece, tiles, (hipStream_t)stream) == 0 ? HD_OK : HD_EINVAL;
+}
+
+int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, int step, float* mat, int n, void* stream) {
+    if (n < 0 || nb < 0 || piece < 1 || step < piece) return HD_EINVAL;
+    if (n == 0) return HD_OK;
+    if (!tiles || !tile_of || !mat || nb < 1) return HD_EINVAL;
+    return launch_stitch_pieces(tiles, tile_of, nb, piece, step, mat, n, (hipStream_t)stream) == 0 ? HD_OK : HD_EINVAL;
+}
+
 int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {

@@ -121,6 +121,8 @@ int launch_pack_q(const float* wqkv, const float* g, int C, unsigned short* dst,
 int launch_linattn_q_fused(const float* x, const float* stats, const unsigned short* wq, const unsigned short* wfold, const float* bias,
                            const float* gout, float* out, int B, int HW, int C, hipStream_t st);
 int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st, int permute = 0);
+int launch_split_pieces(const float* mat, int n, const int* origins, int ntiles, int piece, float* tiles, hipStream_t st);
+int launch_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, int step, float* mat, int n, hipStream_t st);
 int launch_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
                         hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);

@@ -185,6 +185,25 @@ int hd_randn(hd_ctx* ctx, float* out, int B, int S, uint64_t seed, uint64_t tile
 int hd_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
                     void* stream);
 
+/* ---- tile producer / stitcher (the data format either side of the path) ---- */
+
+/* Cut the band of piece x piece tiles out of one chromosome's dense contact matrix: what splitPieces
+ * (processdata/PrepareData_linear_sing.py:25-46) does with numpy slices.
+ *   mat      device f32 [n][n], the matrix BEFORE padding; elements past its edge read as 0, which is the
+ *            reference's F.pad to a multiple of piece (:33-38)
+ *   origins  device i32 [ntiles][2], (row, col) of each tile's first element, in output order
+ *            (hicdiff_amd.processdata.tile_origins restates the reference's double loop and band rule :40-43)
+ *   tiles    device f32 [ntiles][piece][piece] (the (ntiles,1,piece,piece) array of Splits/..._full_chr_*.npy)
+ * Only enqueues on the stream; bit-exact (a copy). */
+int hd_split_pieces(const float* mat, int n, const int* origins, int ntiles, int piece, float* tiles, void* stream);
+
+/* The inverse the reference lacks (its evaluation stays on tiles): write sampled tiles back into a dense n x n
+ * matrix.  tile_of is a device i32 [nb][nb] table over the step grid: the index of the tile whose origin is
+ * (kr*step, kc*step), or -1.  Element (r,c) takes the tile element that holds it; else the element that holds (c,r)
+ * (Hi-C maps are symmetric and only upper-triangle tiles are cut); else 0.  step >= piece (tiles do not overlap:
+ * the reference's cut fails for step < piece).  Only enqueues on the stream; bit-exact (a copy). */
+int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, int step, float* mat, int n, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-launch HIP-event timing of the convolution kernels on their launch stream (process-wide;

@@ -48,6 +48,9 @@ def create_parser():
     p.add_argument("--synthetic", type=int, default=64, help="number of synthetic tiles when no --noisy is given")
     p.add_argument("--noisy", default=None, help=".npy of low-coverage tiles (N,1,S,S) in [-1,1]")
     p.add_argument("--target", default=None, help=".npy of high-coverage tiles (N,1,S,S)")
+    p.add_argument("--matrix", default=None, help="Full_Mats .npy of one chromosome in [-1,1]: cut into --tile tiles on the GPU (splitPieces), "
+                   "degraded with --sigma as split_numpy does, denoised, and stitched back into <out>/predict_matrix.npy")
+    p.add_argument("--res", type=int, default=40000, help="bin size of --matrix (sets the band of tiles, PrepareData_linear_sing.py:31,42)")
     p.add_argument("--weights", default=None, help="state_dict written by the reference's train.py")
     p.add_argument("--outdir", default=os.path.join(ROOT, "Outputs_diff"))
     p.add_argument("--seed", type=int, default=1234)
@@ -78,7 +81,15 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if args.noisy:
+    origins = None
+    if args.matrix:
+        from hicdiff_amd.processdata import split_pieces_device
+        full = np.load(args.matrix)
+        tiles_dev, origins = split_pieces_device(torch.from_numpy(np.ascontiguousarray(full, dtype=np.float32)).to(device), args.tile, args.tile, args.res)
+        hq = tiles_dev.cpu()
+        g = torch.Generator().manual_seed(args.seed)
+        lq = hq + (args.sigma if args.sigma <= 1 else 0.1) * torch.randn(hq.shape, generator=g)     # :194-202 with deg='deno'
+    elif args.noisy:
         lq = torch.from_numpy(np.load(args.noisy)).float()
         hq = torch.from_numpy(np.load(args.target)).float() if args.target else torch.zeros_like(lq)
     else:
@@ -140,6 +151,10 @@ def main(argv=None):
         np.save(os.path.join(out, "noisy"), lq.numpy())
         np.save(os.path.join(out, "inds"), np.arange(n, dtype=np.int64))
         print(f"[inference] {n} tiles of 1x{S}x{S} -> {out}")
+        if origins is not None:
+            from hicdiff_amd.processdata import stitch_pieces_device
+            np.save(os.path.join(out, "predict_matrix"), stitch_pieces_device(predict, origins, full.shape[0], args.tile).cpu().numpy())
+            print(f"[inference] stitched {full.shape[0]}x{full.shape[0]} matrix -> {out}/predict_matrix.npy")
         if args.metrics:
             from hicdiff_amd.Utils.metrics import MetricLog
             log, base = MetricLog(), MetricLog()

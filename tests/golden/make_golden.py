@@ -381,7 +381,71 @@ def case_metrics():
     save("metrics", **out)
 
 
+def reference_function(relpath, name, namespace):
+    """Run ONE function of a reference module whose imports cannot be satisfied here (pyrootutils, pytorch_lightning,
+    cooler at the top of processdata/*.py): parse the file where it lies, compile only that function's own definition
+    and execute it with the names it uses.  Nothing of the reference is written anywhere."""
+    import ast
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name)
+    ns = dict(namespace)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def case_tiles():
+    """splitPieces of processdata/PrepareData_linear_sing.py:25-46 (the reference's own function, executed from its file)
+    on small symmetric matrices, and the 'deno' degradation of :194-202 through the reference's MakeFunc."""
+    import tempfile
+    import torch.nn.functional as F
+    from oracle import tiles as OT
+    split = reference_function("processdata/PrepareData_linear_sing.py", "splitPieces", {"np": np, "torch": torch, "F": F})
+    out = {}
+    cases = (("pad40", 150, 40, 40, 40000), ("exact64", 128, 64, 64, 40000), ("band8", 90, 8, 8, 40000), ("res10k", 75, 8, 8, 10000),
+             ("small", 30, 64, 64, 40000), ("gap", 200, 16, 24, 40000), ("overlap", 128, 64, 50, 40000))
+    for tag, n, p, st, res in cases:
+        a = np.random.RandomState(n + p).rand(n, n).astype(np.float32)
+        m = (2 * ((a + a.T) / 2) ** 3 - 1).astype(np.float32)
+        with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+            np.save(f.name, m)
+            ref = split(f.name, p, st, res)
+        mine = OT.split_pieces(m, p, st, res)
+        org, bound = OT.tile_origins(n, p, st, res)
+        assert ref.shape == mine.shape and ref.dtype == mine.dtype and np.array_equal(ref, mine), tag
+        print(f"  [split {tag}] oracle == reference, {ref.shape[0]} tiles of {p}x{p} from {n}x{n} (padded {bound})")
+        out[f"{tag}_args"] = np.asarray([n, p, st, res], dtype=np.int64)
+        out[f"{tag}_mat"], out[f"{tag}_tiles"], out[f"{tag}_origins"] = m, ref, org
+    # a map smaller than one step of the walk is impossible (padding makes at least one tile); n = 0 is the empty case
+    with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+        np.save(f.name, np.zeros((0, 0), np.float32))
+        ref = split(f.name, 8, 8, 40000)
+    assert ref.shape == OT.split_pieces(np.zeros((0, 0), np.float32), 8, 8, 40000).shape == (0, 1)
+    out["empty_shape"] = np.asarray(ref.shape, dtype=np.int64)
+    # ragged: step < piece with a last tile past the padded edge -> the reference raises ValueError
+    with tempfile.NamedTemporaryFile(suffix=".npy") as f:
+        np.save(f.name, np.zeros((100, 100), np.float32))
+        try:
+            split(f.name, 40, 20, 40000)
+            raised = False
+        except ValueError:
+            raised = True
+    assert raised
+    out["ragged_raises"] = np.asarray([100, 40, 20, 40000], dtype=np.int64)
+    # degradation: noisy / sample of split_numpy (:194-202) with deg='deno'
+    t = torch.from_numpy(out["pad40_tiles"])
+    Hf = MakeFunc(deg="deno", image_channel=1, image_size=40, device=t.device)
+    z = gauss(77, (t.shape[0], 1600))
+    data = Hf.H(t) + 0.1 * z
+    pinv = Hf.H_pinv(data).view(t.shape[0], 1, 40, 40)
+    on, os_ = OT.degrade(t.numpy(), 0.1, z.numpy())
+    assert np.array_equal(on, pinv.numpy()) and np.array_equal(os_, data.numpy())
+    out["deg_z"], out["deg_noisy"], out["deg_sample"] = z, pinv, data
+    save("tiles", **out)
+
+
 CASES = {
+    "tiles": case_tiles,
     "metrics": case_metrics,
     "inventory": case_param_inventory,
     "schedules": case_schedules,

@@ -1,5 +1,6 @@
 """Kernel-level parity on the GPU: the implicit-GEMM convolution (every loader / geometry mode the
 networks use) against torch CPU fp32 conv2d, through the test-only C entry point hd_debug_conv."""
+import os
 import ctypes as C
 
 import pytest
@@ -261,3 +262,96 @@ def test_linear_attention_q_chain_fused(B, S):
     assert rel_err(ref, outs[0]) < 1e-4
     for o2 in outs[1:]:
         assert torch.equal(outs[0], o2)
+
+
+TILE_CASES = ["pad40", "exact64", "band8", "res10k", "small", "gap", "overlap"]
+
+
+@pytest.mark.parametrize("tag", TILE_CASES)
+def test_split_pieces_golden(tag, tmp_path):
+    """hd_split_pieces through the reference's splitPieces signature, bit for bit against the arrays the reference's own
+    function cut (tests/golden/make_golden.py::case_tiles), from a file and from a device tensor; then the stitch back."""
+    import os
+    import numpy as np
+    from _util import GOLDEN
+    from hicdiff_amd import processdata as PD
+    from oracle import tiles as OT
+    g = np.load(os.path.join(GOLDEN, "tiles.npz"))
+    n, p, st, res = (int(v) for v in g[f"{tag}_args"])
+    fn = str(tmp_path / "GSE131811_mat_full_chr_1_40000.npy")
+    np.save(fn, g[f"{tag}_mat"])
+    got = PD.splitPieces(fn, p, st, res)
+    assert got.dtype == g[f"{tag}_tiles"].dtype and got.shape == g[f"{tag}_tiles"].shape and np.array_equal(got, g[f"{tag}_tiles"])
+    dev, org = PD.split_pieces_device(torch.from_numpy(g[f"{tag}_mat"]).cuda(), p, st, res)
+    assert np.array_equal(dev.cpu().numpy(), g[f"{tag}_tiles"]) and np.array_equal(org, g[f"{tag}_origins"])
+    if st >= p:
+        back = PD.stitch_pieces_device(dev, org, n, st).cpu().numpy()
+        assert np.array_equal(back, OT.stitch_pieces(g[f"{tag}_tiles"], org, n))
+        assert np.array_equal(PD.stitchPieces(got, n, p, st, res), back)
+        # asymmetric tiles (a sampler's output need not be symmetric): held elements win over mirrored ones
+        t2 = rnd(5, *dev.shape)
+        assert np.array_equal(PD.stitch_pieces_device(t2.cuda(), org, n, st).cpu().numpy(), OT.stitch_pieces(t2.numpy(), org, n))
+    else:
+        with pytest.raises(ValueError):
+            PD.stitch_pieces_device(dev, org, n, st)
+
+
+@pytest.mark.parametrize("n,p,res", [(1000, 64, 40000), (1537, 40, 40000), (2050, 64, 10000), (777, 16, 20000)])
+def test_split_stitch_round_trip_large(n, p, res):
+    """Size-independent properties at chromosome scale: split == oracle; stitch(split(M)) == M inside the band and 0
+    outside for a symmetric M; the result is symmetric; unaligned pitches (n % 4 != 0) take the scalar path."""
+    import numpy as np
+    from hicdiff_amd import processdata as PD
+    from oracle import tiles as OT
+    a = rnd(n, n, n).numpy()
+    m = np.ascontiguousarray((a + a.T) / 2)
+    dev, org = PD.split_pieces_device(torch.from_numpy(m).cuda(), p, p, res)
+    assert np.array_equal(dev.cpu().numpy(), OT.split_pieces(m, p, p, res))
+    back = PD.stitch_pieces_device(dev, org, n).cpu().numpy()
+    assert np.array_equal(back, OT.stitch_pieces(dev.cpu().numpy(), org, n))
+    band = OT.stitch_pieces(np.ones((len(org), p, p), np.float32), org, n) > 0
+    assert np.array_equal(back[band], m[band]) and not back[~band].any() and np.array_equal(back, back.T)
+
+
+def test_tile_module_writes_the_reference_layout(tmp_path):
+    """GSE130711Module.split_numpy: Splits/GSE131811_{full,noisy,sample}_chr_<c>_<res>_piece_<S>.npy with the reference's
+    shapes, the 'deno' degradation under the host generator, and the chromosome splits of the dataset."""
+    import numpy as np
+    from hicdiff_amd import processdata as PD
+    from oracle import tiles as OT
+
+    class Two(PD.GSE130711Module):                       # two chromosomes are enough for the layout
+        chromosomes = (1, 2)
+        ready_count = 1
+        splits = {"all": (1, 2), "train": (1,), "val": (2,), "test": (1, 2)}
+
+    dm = Two(batch_size=4, res=40000, piece_size=40, sigma_0=0.1, root=tmp_path)
+    assert dm.dirname == f"{tmp_path}/DataFull/DataFull_Human_cell1_40000_deno_0.1"
+    os.makedirs(dm.dirname + "/Full_Mats")
+    mats = {}
+    for c, n in ((1, 130), (2, 95)):
+        a = rnd(c, n, n).numpy()
+        mats[c] = np.ascontiguousarray(np.clip((a + a.T) / 4, -1, 1))
+        np.save(f"{dm.dirname}/Full_Mats/GSE131811_mat_full_chr_{c}_40000.npy", mats[c])
+    torch.manual_seed(11)
+    dm.prepare_data()
+    torch.manual_seed(11)
+    for c in (1, 2):
+        full = np.load(f"{dm.dirname}/Splits/GSE131811_full_chr_{c}_40000_piece_40.npy")
+        noisy = np.load(f"{dm.dirname}/Splits/GSE131811_noisy_chr_{c}_40000_piece_40.npy")
+        samp = np.load(f"{dm.dirname}/Splits/GSE131811_sample_chr_{c}_40000_piece_40.npy")
+        ref = OT.split_pieces(mats[c], 40, 40, 40000)
+        assert np.array_equal(full, ref) and noisy.shape == full.shape and samp.shape == (len(full), 1600)
+        z = torch.randn(len(full), 1600)                  # the same host generator draws, in the same order
+        on, os_ = OT.degrade(ref, 0.1, z.numpy())
+        assert np.array_equal(noisy, on) and np.array_equal(samp, os_)
+    dm.setup("test")
+    lq, hq, sm, info = next(iter(dm.test_dataloader()))
+    assert lq.shape == hq.shape == (4, 1, 40, 40) and sm.shape == (4, 1600) and info.tolist() == [1, 1, 1, 1]
+    assert len(dm.test_set) == len(OT.tile_origins(130, 40, 40, 40000)[0]) + len(OT.tile_origins(95, 40, 40, 40000)[0])
+    dm.setup(2)
+    assert set(dm.test_set.info.tolist()) == {2}
+    with pytest.raises(NotImplementedError):
+        dm.extract_constraint_mats()
+    with pytest.raises(RuntimeError):
+        PD.split_pieces_device(torch.zeros(8, 8), 8, 8, 40000)   # CPU tensor: no fallback

@@ -283,3 +283,25 @@ def test_inference_cli_writes_reference_output_layout(tmp_path, precision):
         assert np.load(outs[0] / (f + ".npy")).shape == shape
     pred2 = inference.main(["-u", "", "--timesteps", "50", "--schedule", "linear"] + common)
     assert pred2.shape == (5, 1, 16, 16) and torch.isfinite(pred2).all()
+
+
+def test_inference_cli_whole_chromosome(tmp_path, precision):
+    """inference.py --matrix: split on the GPU -> degrade -> DDRM -> stitch; the tiles written are the reference's cut
+    of the matrix, and the stitched prediction is exactly the predicted tiles laid back (symmetric outside diagonal tiles)."""
+    if precision != "bf16x3":
+        pytest.skip("one arithmetic mode is enough for the driver")
+    import inference
+    from oracle import tiles as OT
+    n = 70
+    g = torch.Generator().manual_seed(3)
+    a = 2 * torch.rand((n, n), generator=g) ** 3 - 1
+    m = ((a + a.T) / 2).numpy()
+    np.save(tmp_path / "chr.npy", m)
+    pred = inference.main(["-u", "1", "--sampling-steps", "5", "--resnet-blocks", "2", "--tile", "16", "-b", "8", "-s", "0.1",
+                           "--matrix", str(tmp_path / "chr.npy"), "--outdir", str(tmp_path / "out")])
+    out = next((tmp_path / "out").iterdir())
+    ref_tiles = OT.split_pieces(m, 16, 16, 40000)
+    assert np.array_equal(np.load(out / "target.npy"), ref_tiles) and pred.shape == ref_tiles.shape
+    mat = np.load(out / "predict_matrix.npy")
+    assert mat.shape == (n, n)
+    assert np.array_equal(mat, OT.stitch_pieces(np.load(out / "predict.npy"), OT.tile_origins(n, 16, 16, 40000)[0], n))

@@ -163,3 +163,40 @@ def test_metrics_oracle_reproduces_reference_ssim_and_batch_values():
         assert abs(m["snr"] - float(g[f"{tag}_snr"])) <= 1e-5 * abs(float(g[f"{tag}_snr"]))
         assert abs(m["pcc"] - float(g[f"{tag}_pcc"])) < 1e-6
         assert abs(m["psnr"] - float(g[f"{tag}_psnr"])) < 1e-4
+
+
+TILE_CASES = ["pad40", "exact64", "band8", "res10k", "small", "gap", "overlap"]
+
+
+@pytest.mark.parametrize("tag", TILE_CASES)
+def test_tiles_oracle_reproduces_reference_split(tag):
+    """oracle/tiles.py against the arrays the reference's own splitPieces cut (make_golden.py::case_tiles), bit for bit;
+    the host side's tile_origins (pure integer logic, no GPU) must list the same tiles in the same order."""
+    from oracle import tiles as OT
+    from hicdiff_amd.processdata import tile_origins
+    g = np.load(os.path.join(GOLDEN, "tiles.npz"))
+    n, p, st, res = (int(v) for v in g[f"{tag}_args"])
+    mine = OT.split_pieces(g[f"{tag}_mat"], p, st, res)
+    assert mine.dtype == g[f"{tag}_tiles"].dtype and np.array_equal(mine, g[f"{tag}_tiles"])
+    org, bound = tile_origins(n, p, st, res)
+    assert np.array_equal(org, g[f"{tag}_origins"]) and bound % p == 0 and bound - n < p
+    if st >= p:                                                    # the stitch definition: a symmetric map comes back inside the band
+        back = OT.stitch_pieces(mine, org, n)
+        held = OT.stitch_pieces(np.ones_like(mine), org, n) > 0
+        assert np.array_equal(back[held], g[f"{tag}_mat"][held]) and not back[~held].any()
+        assert np.array_equal(back, back.T)
+
+
+def test_tiles_edge_cases_and_degradation():
+    from oracle import tiles as OT
+    from hicdiff_amd.processdata import tile_origins
+    g = np.load(os.path.join(GOLDEN, "tiles.npz"))
+    assert tuple(g["empty_shape"]) == (0, 1) == OT.split_pieces(np.zeros((0, 0), np.float32), 8, 8, 40000).shape
+    assert len(tile_origins(0, 8, 8, 40000)[0]) == 0
+    n, p, st, res = (int(v) for v in g["ragged_raises"])
+    with pytest.raises(ValueError):
+        OT.split_pieces(np.zeros((n, n), np.float32), p, st, res)
+    with pytest.raises(ValueError):
+        tile_origins(n, p, st, res)
+    noisy, sample = OT.degrade(g["pad40_tiles"], 0.1, g["deg_z"])
+    assert np.array_equal(noisy, g["deg_noisy"]) and np.array_equal(sample, g["deg_sample"])
