@@ -339,6 +339,24 @@ class DiffusionCore(nn.Module):
             per = per * self.p2_loss_weight.gather(-1, t)
         return per.mean()
 
+    def _native_training(self) -> bool:
+        """Train mode under autograd -> the native training step (hicdiff_amd/_training.py); eval / no_grad -> loss value only."""
+        return self.training and torch.is_grad_enabled() and bool(getattr(self.model, "_native_train", False))
+
+    def _native_loss(self, x_start, cond, t, noise):
+        """loss tensor with `.backward()` (train.py:131-132): forward, loss and every gradient in one engine call."""
+        from ._training import trainer_for
+        if self.objective != "pred_noise":
+            raise NotImplementedError("the reference trains with objective='pred_noise' only")
+        if self.loss_type not in ("l1", "l2"):
+            raise ValueError(f"invalid loss type {self.loss_type}")
+        if float(self.p2_loss_weight.min()) != 1.0 or float(self.p2_loss_weight.max()) != 1.0:
+            raise NotImplementedError("p2_loss_weight_gamma != 0 is not used by the reference's training")
+        tr = trainer_for(self.model, x_start.shape[0], x_start.shape[-1])
+        a_t = self.sqrt_alphas_cumprod.gather(-1, t)
+        s_t = self.sqrt_one_minus_alphas_cumprod.gather(-1, t)
+        return tr.loss_backward(x_start, cond, t, noise, a_t, s_t, self.loss_type == "l2")
+
     def _target(self, x_start, t, noise):
         if self.objective == "pred_noise":
             return noise

@@ -66,7 +66,7 @@ class Engine:
         load_state_dict): the reference recomputes weight standardisation every forward
         (src/hicdiff.py:89-97); here it happens once per weight version."""
         params = list(module.named_parameters())
-        sig = tuple((p.data_ptr(), p._version) for _, p in params)
+        sig = tuple((p.data_ptr(), p._version) for _, p in params) + (module.__dict__.get("_hd_weight_epoch", 0),)
         if sig == self._sig:
             return
         keep, arr = [], (L.HdNamedTensor * len(params))()

@@ -72,6 +72,13 @@ SYMBOLS = {
     "hd_set_graphs": (C.c_int, [_P, C.c_int]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "hd_tile_metrics": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
+    "hd_train_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
+    "hd_train_destroy": (None, [_P]),
+    "hd_train_last_error": (C.c_char_p, [_P]),
+    "hd_train_param_count": (C.c_int, [_P, _P]),
+    "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "hd_train_loss_backward": (C.c_int, [_P] * 9 + [C.c_int, _P, _P]),
+    "hd_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
     "hd_split_pieces": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "hd_stitch_pieces": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
 }

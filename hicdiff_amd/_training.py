@@ -1,0 +1,134 @@
+"""Host side of the native training step (include/hicdiff_hip.h "training step").
+
+The reference trains with `loss = diffusion(x); loss.backward(); optimizer.step(); optimizer.zero_grad()` (train.py:131-134).
+Here the same four lines run on the HIP engine: in train mode `GaussianDiffusion.forward` computes the loss AND every gradient in
+one `hd_train_loss_backward`, and returns a loss tensor whose `.backward()` hands the gradients to the parameters' `.grad`;
+`hicdiff_amd.optim.Adam.step()` is one `hd_adam_step` over the flat buffer.  The module's parameters become views of one flat
+fp32 tensor (state_dict keys, shapes and values unchanged).  torch owns the memory and, for N > 1 GPUs, the one all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+
+class NativeTrainer:
+    """Flat parameter / gradient storage of one eps-network plus the C trainer sized for (B, S)."""
+
+    def __init__(self, model, B: int, S: int):
+        p0 = next(model.parameters())
+        if p0.device.type != "cuda":
+            raise RuntimeError("hicdiff_amd trains on MI355X (HIP) tensors only; there is no CPU fallback")
+        self.lib, self.model, self.device, self.B, self.S = L.load(), model, p0.device, B, S
+        self.h = C.c_void_p()
+        arch = model._arch()
+        with torch.cuda.device(self.device):
+            rc = self.lib.hd_train_create(C.byref(self.h), self.device.index or 0, C.byref(arch), B, S)
+        if rc != 0:
+            msg = (self.lib.hd_train_last_error(None) or b"").decode()
+            if rc == L.HD_EINVAL:
+                raise NotImplementedError(msg or "native training is not available for this network")
+            raise L.HdError(rc, msg)
+        total = C.c_longlong()
+        n = self.lib.hd_train_param_count(self.h, C.byref(total))
+        self.slots = []
+        for i in range(n):
+            name, off, shape, nd = C.c_char_p(), C.c_longlong(), (C.c_longlong * 4)(), C.c_int()
+            self.lib.hd_train_param_slot(self.h, i, C.byref(name), C.byref(off), shape, C.byref(nd))
+            self.slots.append((name.value.decode(), off.value, tuple(shape[k] for k in range(nd.value))))
+        self.flat = torch.zeros(total.value, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros_like(self.flat)
+        self.loss = torch.zeros((), dtype=torch.float32, device=self.device)
+        named = dict(model.named_parameters())
+        if set(named) != {s[0] for s in self.slots}:
+            raise RuntimeError("parameter names of the module and of the trainer layout differ")
+        self.params = []
+        for name, off, shape in self.slots:                      # re-seat every parameter on the flat buffer
+            p = named[name]
+            if tuple(p.shape) != shape:
+                raise RuntimeError(f"{name}: module shape {tuple(p.shape)} != trainer shape {shape}")
+            view = self.flat[off:off + p.numel()].view(shape)
+            view.copy_(p.detach())
+            p.data = view
+            p._hd_flat = (self, off)
+            self.params.append(p)
+        self.anchor = torch.zeros((), device=self.device, requires_grad=True)      # gives the returned loss a grad_fn
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.h.value:
+                self.lib.hd_train_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    def still_seated(self) -> bool:
+        """False after e.g. load_state_dict(assign=True) or .to(): the parameters left the flat buffer."""
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * off for p, (_, off, _) in zip(self.params, self.slots))
+
+    def grad_view(self, i):
+        name, off, shape = self.slots[i]
+        n = 1
+        for s in shape:
+            n *= s
+        return self.grads[off:off + n].view(shape)
+
+    def loss_backward(self, x_start, cond, t, noise, a_t, s_t, l2: bool):
+        B, _, S, _ = x_start.shape
+        if (B, S) != (self.B, self.S):
+            raise ValueError(f"trainer sized for batches of {self.B} tiles of {self.S}x{self.S}, got {B} of {S}x{S}")
+        f = lambda v: None if v is None else v.detach().to(torch.float32).contiguous()
+        x_start, cond, noise, a_t, s_t = f(x_start), f(cond), f(noise), f(a_t), f(s_t)
+        t = t.to(torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            rc = self.lib.hd_train_loss_backward(self.h, _ptr(self.flat), _ptr(self.grads), _ptr(x_start), _ptr(cond), _ptr(t), _ptr(noise),
+                                                 _ptr(a_t), _ptr(s_t), 1 if l2 else 0, _ptr(self.loss), st)
+        if rc != 0:
+            raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
+        return _NativeLoss.apply(self.anchor, self, self.loss.clone())
+
+    def weights_changed(self):
+        self.model.__dict__["_hd_weight_epoch"] = self.model.__dict__.get("_hd_weight_epoch", 0) + 1
+
+
+class _NativeLoss(torch.autograd.Function):
+    """The gradients already exist when the loss is returned; backward() only publishes them as `.grad`."""
+
+    @staticmethod
+    def forward(ctx, anchor, trainer, value):
+        ctx.trainer = trainer
+        return value
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        tr = ctx.trainer
+        one = bool((grad_out == 1).item())
+        if not one:
+            tr.grads.mul_(grad_out)
+        for i, p in enumerate(tr.params):
+            g = tr.grad_view(i)
+            if p.grad is None:
+                p.grad = g                        # a view of the flat gradient buffer: Adam below reads it in place
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)                    # accumulation over several backward() calls, as autograd would
+        return None, None, None
+
+
+def trainer_for(model, B: int, S: int) -> NativeTrainer:
+    tr = model.__dict__.get("_hd_trainer")
+    if tr is None or (tr.B, tr.S) != (B, S) or tr.device != next(model.parameters()).device or not tr.still_seated():
+        if tr is not None:
+            for p in tr.params:
+                p.grad = None
+        tr = NativeTrainer(model, B, S)
+        model.__dict__["_hd_trainer"] = tr
+    return tr

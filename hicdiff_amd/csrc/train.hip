@@ -1,0 +1,737 @@
+// Native training step of the hicedrn eps-network: p_losses forward with saved
+// activations, hand-written backward, fused Adam.  Reference: train.py:109-190 (loss = diffusion(x); loss.backward();
+// optim.Adam(lr=2e-5).step()), src/hicdiff.py:711-755, src/hicdiff_condition.py:715-750, src/model/hicedrn_Diff.py:169-289.
+//
+// Convolutions: the forward and the data gradient run on the implicit-GEMM kernel of conv_bf16x3_kernel.h (the data
+// gradient is the same convolution with the weight flipped and transposed).  The weight gradient is a split-bf16 x3 NT
+// GEMM over pixels: both operands are first rewritten channel-major as bf16 hi / lo images over a PADDED pixel axis
+// (one zero row per sample, eight zero columns per row), so that the nine taps become nine constant shifts of one flat
+// axis: the row shift is applied to the activation pointer, the column shift is baked into three copies of the
+// gradient operand.  Everything is deterministic (split-K partials are reduced in a fixed order, no atomics).
+#include "hd_common.h"
+#include "../../include/hicdiff_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hd_set_error(std::string(what) + ": " + hipGetErrorString(e)); return -3; }
+    return 0;
+}
+
+// ---- weight-gradient operands ---------------------------------------------------------------------------------------
+// in: NHWC fp32 [B][H][W][C].  out: bf16 hi / lo images [NSHIFT*C][ld]; pixel (b,y,x) of channel c lands at
+// k = guard + (b*(H+1) + y + 1) * P + 8 + x (+ dx for copy dx+1 of NSHIFT == 3).  Pad positions are never written: the
+// buffers are zeroed once.  mode 1 applies the block's FiLM + SiLU on the way in (the activation between the two uses of
+// the block's convolution is recomputed instead of stored).  colpart (optional): per-row channel sums for the bias gradient.
+template <int NSHIFT>
+__global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
+                                                      unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
+                                                      const float* __restrict__ film, int film_bs, float* __restrict__ colpart) {
+    // pixel-major [x][C+2] ushorts: the channel-per-thread writes and the pixel-per-lane reads are both conflict-free
+    __shared__ unsigned short sh_hi[64 * 258], sh_lo[64 * 258];
+    const int Cp = C + 2;
+    const int b = blockIdx.x / H, y = blockIdx.x % H, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) {
+        float sc = 0.f, shf = 0.f, sum = 0.f;
+        if (mode == 1) { sc = film[(size_t)b * film_bs + c] + 1.f; shf = film[(size_t)b * film_bs + C + c]; }
+        const float* src = in + ((size_t)(b * H + y) * W) * C + c;
+        for (int x = 0; x < W; ++x) {
+            float v = src[(size_t)x * C];
+            if (mode == 1) v = silu_f(v * sc + shf);
+            sum += v;
+            const __bf16 hh = (__bf16)v;
+            const __bf16 ll = (__bf16)(v - (float)hh);
+            sh_hi[x * Cp + c] = __builtin_bit_cast(unsigned short, hh);
+            sh_lo[x * Cp + c] = __builtin_bit_cast(unsigned short, ll);
+        }
+        if (colpart) colpart[(size_t)blockIdx.x * C + c] = sum;
+    }
+    __syncthreads();
+    const int lane = tid & 63, w = tid >> 6;
+    const size_t kbase = guard + ((size_t)b * (H + 1) + y + 1) * P + 8;
+    if (lane < W) {
+        for (int c = w; c < C; c += 4) {
+            const unsigned short vh = sh_hi[lane * Cp + c], vl = sh_lo[lane * Cp + c];
+#pragma unroll
+            for (int s = 0; s < NSHIFT; ++s) {
+                const int dx = NSHIFT == 3 ? s - 1 : 0;
+                const size_t o = ((size_t)s * C + c) * ld + kbase + lane + dx;
+                hi[o] = vh; lo[o] = vl;
+            }
+        }
+    }
+}
+
+// partial[(split*3 + dyi)][M][N] = sum over this split's k of A[m][k + (dyi-1)*P] * B[n][k], split-bf16 x3.
+// 128x128 tile per workgroup, 4 waves as 2x2 of 64x64, K slices of 64 staged through LDS (row pitch 144 B: the 16-byte
+// operand reads of 16 consecutive rows fall in distinct banks), next slice prefetched into registers under the MFMAs.
+__global__ __launch_bounds__(256, 2) void nt_gemm_bf16x3_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
+                                                             const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
+                                                             size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int N,
+                                                             float* __restrict__ partial) {
+    constexpr int BM = 128, KS = 64, PITCH = KS * 2 + 16;
+    __shared__ __attribute__((aligned(16))) char sm[4][BM * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = w >> 1, wn = w & 1;
+    // Workgroups that stream the same k range share an XCD (blockIdx round-robins over the 8 XCDs), so the 12 tiles of a split
+    // re-read its operand slices from that XCD's L2 instead of from HBM.
+    const int per = Mtiles * Ntiles;
+    int split, inner;
+    if ((nsplit & 7) == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
+    else { split = blockIdx.x / per; inner = blockIdx.x % per; }
+    const int nt = inner % Ntiles, mt = inner / Ntiles;
+    const size_t k0 = guard + (size_t)split * kchunk;
+    const int nslices = (int)(kchunk / KS);
+    // this thread's four 16-byte chunks of every 128 x 64 operand slice: rows lrow + 32 j, chunk lch
+    const int lrow = tid >> 3, lch = tid & 7;
+    const size_t goff = (size_t)lrow * ld + lch * 8;
+    const int loff = lrow * PITCH + lch * 16;
+    for (int dyi = 0; dyi < 3; ++dyi) {
+    const size_t ka = (size_t)((long)k0 + (long)(dyi - 1) * P);       // >= 0: guard >= P
+    const unsigned short* pAh = Ahi + (size_t)mt * BM * ld + ka + goff;
+    const unsigned short* pAl = Alo + (size_t)mt * BM * ld + ka + goff;
+    const unsigned short* pBh = Bhi + (size_t)nt * BM * ld + k0 + goff;
+    const unsigned short* pBl = Blo + (size_t)nt * BM * ld + k0 + goff;
+    // sixteen named registers, not arrays: indexed arrays of prefetch registers end up in scratch with a wait after every load
+    uint4 rAh0, rAh1, rAh2, rAh3, rAl0, rAl1, rAl2, rAl3, rBh0, rBh1, rBh2, rBh3, rBl0, rBl1, rBl2, rBl3;
+#define HD_LD(p, j, K) (*reinterpret_cast<const uint4*>((p) + (size_t)(j) * 32 * ld + (K)))
+#define HD_GLOAD(K)                                                                                                     \
+    rAh0 = HD_LD(pAh, 0, K); rAl0 = HD_LD(pAl, 0, K); rBh0 = HD_LD(pBh, 0, K); rBl0 = HD_LD(pBl, 0, K);                 \
+    rAh1 = HD_LD(pAh, 1, K); rAl1 = HD_LD(pAl, 1, K); rBh1 = HD_LD(pBh, 1, K); rBl1 = HD_LD(pBl, 1, K);                 \
+    rAh2 = HD_LD(pAh, 2, K); rAl2 = HD_LD(pAl, 2, K); rBh2 = HD_LD(pBh, 2, K); rBl2 = HD_LD(pBl, 2, K);                 \
+    rAh3 = HD_LD(pAh, 3, K); rAl3 = HD_LD(pAl, 3, K); rBh3 = HD_LD(pBh, 3, K); rBl3 = HD_LD(pBl, 3, K);
+#define HD_ST(m, j, r) *reinterpret_cast<uint4*>(sm[m] + loff + (j) * 32 * PITCH) = r
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    HD_GLOAD(0)
+    for (int s = 0; s < nslices; ++s) {
+        HD_ST(0, 0, rAh0); HD_ST(0, 1, rAh1); HD_ST(0, 2, rAh2); HD_ST(0, 3, rAh3);
+        HD_ST(1, 0, rAl0); HD_ST(1, 1, rAl1); HD_ST(1, 2, rAl2); HD_ST(1, 3, rAl3);
+        HD_ST(2, 0, rBh0); HD_ST(2, 1, rBh1); HD_ST(2, 2, rBh2); HD_ST(2, 3, rBh3);
+        HD_ST(3, 0, rBl0); HD_ST(3, 1, rBl1); HD_ST(3, 2, rBl2); HD_ST(3, 3, rBl3);
+        __syncthreads();
+        // unconditional (the last iteration re-reads its own slice): a conditional prefetch sends these registers to scratch
+        { const size_t kn = (size_t)min(s + 1, nslices - 1) * KS; HD_GLOAD(kn) }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int ro = (wm * 64 + t * 32 + l31) * PITCH + ks * 32 + half * 16;
+                const int co = (wn * 64 + t * 32 + l31) * PITCH + ks * 32 + half * 16;
+                ah[t] = *reinterpret_cast<const bf16x8*>(sm[0] + ro);
+                al[t] = *reinterpret_cast<const bf16x8*>(sm[1] + ro);
+                bh[t] = *reinterpret_cast<const bf16x8*>(sm[2] + co);
+                bl[t] = *reinterpret_cast<const bf16x8*>(sm[3] + co);
+            }
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+#undef HD_GLOAD
+#undef HD_LD
+#undef HD_ST
+    float* out = partial + ((size_t)(split * 3 + dyi) * M) * N;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int n = nt * BM + wn * 64 + tn * 32 + l31;
+                out[(size_t)m * N + n] = acc[tm][tn][r];
+            }
+    }
+}
+
+// dW[co][ci][ky][kx] (torch layout) (+)= scale * sum_split partial[split][ky][ci][kx*F + co]
+__global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ partial, int nsplit, int F, float scale, int accumulate,
+                                                        float* __restrict__ dW) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [3][F][3F]
+    const size_t per = (size_t)3 * F * 3 * F;
+    if (i >= per) return;
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * per + i];
+    const int n = (int)(i % (3 * F)), ci = (int)((i / (3 * F)) % F), ky = (int)(i / ((size_t)3 * F * F));
+    const int kx = n / F, co = n % F;
+    float* d = dW + (((size_t)co * F + ci) * 3 + ky) * 3 + kx;
+    *d = (accumulate ? *d : 0.f) + scale * s;
+}
+
+// data-gradient weight: Wt[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (both torch layout)
+__global__ __launch_bounds__(256) void flip_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wt) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Cout * Cin * 9) return;
+    const int tap = (int)(i % 9), co = (int)((i / 9) % Cout), ci = (int)(i / ((size_t)9 * Cout));
+    wt[i] = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------------
+// a = silu(u * (scale + 1) + shift), film = [B][2C] (scale | shift)
+__global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* __restrict__ u, const float* __restrict__ film, int film_bs, int HW, int C,
+                                                            size_t n4, float* __restrict__ a) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t e = i * 4;
+    const int c = (int)(e % C), b = (int)(e / ((size_t)HW * C));
+    const float4 v = *reinterpret_cast<const float4*>(u + e);
+    const float4 sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c);
+    const float4 sh = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + C + c);
+    float4 o;
+    o.x = silu_f(v.x * (sc.x + 1.f) + sh.x); o.y = silu_f(v.y * (sc.y + 1.f) + sh.y);
+    o.z = silu_f(v.z * (sc.z + 1.f) + sh.z); o.w = silu_f(v.w * (sc.w + 1.f) + sh.w);
+    *reinterpret_cast<float4*>(a + e) = o;
+}
+
+// g (in: dL/da * 1/gscale; out: dL/du), u: pre-FiLM conv output.  v = u (sc+1) + sh; dv = gscale * g * silu'(v);
+// du = dv (sc+1); part[(b*nchunk + chunk)][0][c] = sum dv*u (d scale), [1][c] = sum dv (d shift).
+__global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ film,
+                                                            int film_bs, int HW, int C, int chunk, float gscale, float* __restrict__ part) {
+    const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
+    const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float sc = film[(size_t)b * film_bs + c] + 1.f, sh = film[(size_t)b * film_bs + C + c];
+        float s_scale = 0.f, s_shift = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const size_t e = ((size_t)b * HW + p) * C + c;
+            const float uu = u[e];
+            const float v = uu * sc + sh;
+            const float sg = sigmoid_f(v);
+            const float dv = gscale * g[e] * (sg * (1.f + v * (1.f - sg)));
+            s_scale += dv * uu; s_shift += dv;
+            g[e] = dv * sc;
+        }
+        float* d = part + ((size_t)(b * nchunk + ck) * 2) * C;
+        d[c] = s_scale; d[C + c] = s_shift;
+    }
+}
+
+// out[batch][col] (+)= scale * sum_row in[batch][row][col]
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, int nrows, int ncols, float scale, int accumulate,
+                                                       float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x, bt = blockIdx.y;
+    if (col >= ncols) return;
+    const float* p = in + (size_t)bt * nrows * ncols + col;
+    float s = 0.f;
+    for (int r = 0; r < nrows; ++r) s += p[(size_t)r * ncols];
+    float* d = out + (size_t)bt * ncols + col;
+    *d = (accumulate ? *d : 0.f) + scale * s;
+}
+
+// ---- small dense layers (time MLP, FiLM projections); weights in torch layout W[N][K] ---------------------------------
+// act: 0 none, 1 SiLU, 2 exact GELU applied to X on the way in
+__device__ __forceinline__ float act_f(float x, int act) {
+    return act == 1 ? silu_f(x) : act == 2 ? 0.5f * x * (1.f + erff(x * 0.70710678118654752f)) : x;
+}
+__device__ __forceinline__ float dact_f(float x, int act) {
+    if (act == 1) { const float s = sigmoid_f(x); return s * (1.f + x * (1.f - s)); }
+    if (act == 2) return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    return 1.f;
+}
+
+// Y[b][n] = bias[n] + sum_k act(X[b][k]) * W[n][k]; one wave per output column n, lanes over k
+__global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
+                                                      int Bn, int K, int N, int act, float* __restrict__ Y, int ldy) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    for (int b = 0; b < Bn; ++b) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += act_f(X[(size_t)b * ldx + k], act) * W[(size_t)n * K + k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (lane == 0) Y[(size_t)b * ldy + n] = s + bias[n];
+    }
+}
+
+// dW[n][k] = sum_b dY[b][n] * act(X[b][k]);  db[n] = sum_b dY[b][n]
+__global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int Bn, int K, int N,
+                                                        int act, float* __restrict__ dW, float* __restrict__ db) {
+    const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K) {
+        float s = 0.f;
+        for (int b = 0; b < Bn; ++b) s += dY[(size_t)b * ldy + n] * act_f(X[(size_t)b * ldx + k], act);
+        dW[(size_t)n * K + k] = s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < Bn; ++b) s += dY[(size_t)b * ldy + n];
+        db[n] = s;
+    }
+}
+
+// dX[b][k] (+)= (sum_n dY[b][n] * W[n][k]) * act'(Xpre[b][k])   (act' only when Xpre is given)
+__global__ __launch_bounds__(256) void lin_bwd_x_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ W, int Bn, int K, int N,
+                                                        const float* __restrict__ Xpre, int ldx, int act, int accumulate, float* __restrict__ dX, int lddx) {
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) s += dY[(size_t)b * ldy + n] * W[(size_t)n * K + k];
+    if (Xpre) s *= dact_f(Xpre[(size_t)b * ldx + k], act);
+    float* d = dX + (size_t)b * lddx + k;
+    *d = (accumulate ? *d : 0.f) + s;
+}
+
+// x *= act'(pre) elementwise (used to turn d silu(t) into d t)
+__global__ __launch_bounds__(256) void dact_mul_kernel(float* __restrict__ x, const float* __restrict__ pre, size_t n, int act) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= dact_f(pre[i], act);
+}
+
+// SinusoidalPosEmb (src/model/hicedrn_Diff.py:122-134): emb[b] = [sin(t f_k), cos(t f_k)], f_k = exp(-k ln(1e4)/(half-1))
+__global__ __launch_bounds__(256) void sin_emb_kernel(const long long* __restrict__ t, int dim, float* __restrict__ emb) {
+    const int b = blockIdx.x, half = dim / 2;
+    const float tv = (float)t[b];
+    for (int i = threadIdx.x; i < dim; i += 256) {
+        const int k = i < half ? i : i - half;
+        const float a = tv * expf((float)k * -(9.210340371976184f / (float)(half - 1)));
+        emb[(size_t)b * dim + i] = i < half ? sinf(a) : cosf(a);
+    }
+}
+
+// ---- first / last convolution weight gradients (1-2 channels on one side) -----------------------------------------------
+// part[(b*nrb + rb)][c][j*9 + tap] = sum over the row block of big[p][c] * small_j[p + sign*(tap offset)]
+__global__ __launch_bounds__(256) void small_conv_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ s0, const float* __restrict__ s1,
+                                                               int J, int S, int C, int RB, int sign, float* __restrict__ part) {
+    extern __shared__ float sm[];                           // [J][RB+2][S+2]
+    const int b = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x, y0 = rb * RB, LW = S + 2, LH = RB + 2;
+    for (int i = threadIdx.x; i < J * LH * LW; i += 256) {
+        const int j = i / (LH * LW), r = (i / LW) % LH, x = i % LW;
+        const int yy = y0 + r - 1, xx = x - 1;
+        const float* src = j == 0 ? s0 : s1;
+        sm[i] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? src[((size_t)b * S + yy) * S + xx] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float acc[2][9];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
+        for (int yy = 0; yy < RB && y0 + yy < S; ++yy)
+            for (int x = 0; x < S; ++x) {
+                const float v = big[(((size_t)b * S + y0 + yy) * S + x) * C + c];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (j < J)
+#pragma unroll
+                        for (int t = 0; t < 9; ++t)
+                            acc[j][t] += v * sm[(j * LH + yy + 1 + sign * (t / 3 - 1)) * LW + x + 1 + sign * (t % 3 - 1)];
+            }
+        float* d = part + ((size_t)(b * nrb + rb) * C + c) * (J * 9);
+        for (int j = 0; j < J; ++j)
+            for (int t = 0; t < 9; ++t) d[j * 9 + t] = acc[j][t];
+    }
+}
+
+// ---- loss ---------------------------------------------------------------------------------------------------------
+// per[b] = mean_i f(out - eps); dout = f'(out - eps) / (B * n)   (l2: f = d^2; l1: f = |d|; p2 weight == 1)
+// per[b] = per-sample loss, per[B + b] = sum of the sample's dout (the last convolution's bias gradient)
+__global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ eps, int n, int B, int l2,
+                                                        float* __restrict__ per, float* __restrict__ dout) {
+    __shared__ float red[256], red2[256];
+    const int b = blockIdx.x;
+    const float inv = 1.f / ((float)B * (float)n);
+    float s = 0.f, sg = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float d = out[(size_t)b * n + i] - eps[(size_t)b * n + i];
+        s += l2 ? d * d : fabsf(d);
+        const float g = l2 ? 2.f * d * inv : (d > 0.f ? inv : d < 0.f ? -inv : 0.f);
+        dout[(size_t)b * n + i] = g;
+        sg += g;
+    }
+    red[threadIdx.x] = s; red2[threadIdx.x] = sg;
+    __syncthreads();
+    for (int m = 128; m >= 1; m >>= 1) {
+        if (threadIdx.x < m) { red[threadIdx.x] += red[threadIdx.x + m]; red2[threadIdx.x] += red2[threadIdx.x + m]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { per[b] = red[0] / (float)n; per[B + b] = red2[0]; }
+}
+__global__ void mean_kernel(const float* __restrict__ per, int B, float* __restrict__ loss, float* __restrict__ dbias) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f, g = 0.f;
+        for (int b = 0; b < B; ++b) { s += per[b]; g += per[B + b]; }
+        *loss = s / (float)B; *dbias = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n4, float* __restrict__ o) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(o)[i] = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+}
+
+// torch.optim.Adam (no weight decay, no amsgrad): train.py:111
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                   float b1, float b2, float eps, float step_size, float inv_sqrt_c2, float gscale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gg = g[i] * gscale;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] -= step_size * mm / (sqrtf(vv) * inv_sqrt_c2 + eps);
+}
+
+}  // namespace
+
+// =====================================================================================================================
+struct hd_trainer {
+    hd_arch_desc arch{};
+    int device = 0, B = 0, S = 0, F = 256, nres = 0, cin0 = 1, tdim = 1024;
+    std::string err;
+    struct Slot { std::string name; size_t off, n; int ndim; long long shape[4]; };
+    std::vector<Slot> slots;
+    size_t nparams = 0;
+    size_t o_head_w = 0, o_head_b = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_bt_w = 0, o_bt_b = 0, o_tail_w = 0, o_tail_b = 0;
+    std::vector<size_t> o_mlp_w, o_mlp_b, o_conv_w, o_conv_b;
+    // device memory
+    std::vector<void*> owned;
+    std::vector<ConvW> fwd, bwd;          // body convs + body_tail (index nres)
+    ConvW tail_fwd;
+    float *wt_tmp = nullptr, *tail_flip = nullptr, *zero_bias = nullptr;
+    // weight-gradient geometry and operands
+    int P = 0, splitK = 1;
+    size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
+    unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
+    float *partial = nullptr, *colpart = nullptr, *ctmp = nullptr;
+    // activations
+    std::vector<float*> X, U;             // X[0..nres], U[0..nres-1]
+    float *Y = nullptr, *out = nullptr, *xt = nullptr, *dout = nullptr, *g0 = nullptr, *g1 = nullptr, *g2 = nullptr, *per = nullptr;
+    float *emb = nullptr, *h1pre = nullptr, *temb = nullptr, *film = nullptr, *dfilm = nullptr, *dst = nullptr, *dh1 = nullptr, *fpart = nullptr,
+          *spart = nullptr;
+};
+
+static thread_local std::string t_err;
+static int tfail(hd_trainer* t, int code, const std::string& msg) { t_err = msg; if (t) t->err = msg; hd_set_error(msg); return code; }
+
+#define TR_TRY(expr)                                                        \
+    do {                                                                    \
+        int rc_ = (expr);                                                   \
+        if (rc_ != 0) return tfail(tr, HD_EHIP, "training step: a launch failed (see hd_last_error)"); \
+    } while (0)
+
+static void add_slot(hd_trainer* t, const std::string& name, std::initializer_list<long long> shape, size_t* off) {
+    hd_trainer::Slot s; s.name = name; s.off = t->nparams; s.ndim = (int)shape.size(); s.n = 1;
+    int i = 0; for (long long d : shape) { s.shape[i++] = d; s.n *= (size_t)d; }
+    for (; i < 4; ++i) s.shape[i] = 1;
+    if (off) *off = s.off;
+    t->nparams += (s.n + 3) & ~(size_t)3;                      // keep every tensor 16-byte aligned in the flat buffer
+    t->slots.push_back(s);
+}
+
+template <class T> static T* dev_alloc(hd_trainer* t, size_t n, bool zero = false) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (zero && hipMemset(p, 0, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    t->owned.push_back(p);
+    return (T*)p;
+}
+
+extern "C" {
+
+const char* hd_train_last_error(const hd_trainer* t) { return t ? t->err.c_str() : t_err.c_str(); }
+
+void hd_train_destroy(hd_trainer* t) {
+    if (!t) return;
+    for (void* p : t->owned) (void)hipFree(p);
+    delete t;
+}
+
+int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, int S) {
+    if (!out || !a) return HD_EINVAL;
+    *out = nullptr;
+    if (a->kind != HD_ARCH_HICEDRN || a->sr3) return tfail(nullptr, HD_EINVAL, "native training covers hicedrn_Diff (unconditional / self_condition); UNet and SR3 are not built yet");
+    if (a->dim != 256 || a->number_resnet < 1) return tfail(nullptr, HD_EINVAL, "hicedrn: n_feat must be 256");
+    if (B < 1 || S < 8 || S > 64 || S % 8) return tfail(nullptr, HD_EINVAL, "training tiles: 8 <= S <= 64, S a multiple of 8");
+    if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, HD_EHIP, "hipSetDevice failed");
+    hd_trainer* t = new hd_trainer();
+    t->arch = *a; t->device = device; t->B = B; t->S = S; t->F = a->dim; t->nres = a->number_resnet; t->cin0 = a->self_condition ? 2 : 1;
+    t->tdim = 4 * t->F;
+    const int F = t->F, n = t->nres;
+    // flat parameter layout = the reference's state_dict order (tests/golden/param_inventory.json)
+    add_slot(t, "head.weight", {F, t->cin0, 3, 3}, &t->o_head_w);
+    add_slot(t, "head.bias", {F}, &t->o_head_b);
+    add_slot(t, "time_mlp.1.weight", {t->tdim, F}, &t->o_t1w);
+    add_slot(t, "time_mlp.1.bias", {t->tdim}, &t->o_t1b);
+    add_slot(t, "time_mlp.3.weight", {t->tdim, t->tdim}, &t->o_t3w);
+    add_slot(t, "time_mlp.3.bias", {t->tdim}, &t->o_t3b);
+    t->o_mlp_w.resize(n); t->o_mlp_b.resize(n); t->o_conv_w.resize(n + 1); t->o_conv_b.resize(n + 1);
+    for (int i = 0; i < n; ++i) {
+        const std::string p = "body." + std::to_string(i);
+        add_slot(t, p + ".mlp.1.weight", {2 * F, t->tdim}, &t->o_mlp_w[i]);
+        add_slot(t, p + ".mlp.1.bias", {2 * F}, &t->o_mlp_b[i]);
+        add_slot(t, p + ".conv.proj.weight", {F, F, 3, 3}, &t->o_conv_w[i]);
+        add_slot(t, p + ".conv.proj.bias", {F}, &t->o_conv_b[i]);
+    }
+    add_slot(t, "body_tail.weight", {F, F, 3, 3}, &t->o_conv_w[n]);
+    add_slot(t, "body_tail.bias", {F}, &t->o_conv_b[n]);
+    add_slot(t, "tail.weight", {1, F, 3, 3}, &t->o_tail_w);
+    add_slot(t, "tail.bias", {1}, &t->o_tail_b);
+    t->o_bt_w = t->o_conv_w[n]; t->o_bt_b = t->o_conv_b[n];
+
+    bool ok = true;
+    auto need = [&](void* p) { if (!p) ok = false; return p; };
+    const size_t wn = (size_t)9 * F * F;
+    t->fwd.resize(n + 1); t->bwd.resize(n + 1);
+    for (int i = 0; i <= n && ok; ++i)
+        for (ConvW* w : {&t->fwd[i], &t->bwd[i]}) {
+            w->KH = w->KW = 3; w->Cin = F; w->Cout = F; w->CoutPad = F; w->ck = 32;
+            w->w = (float*)need(dev_alloc<float>(t, wn));
+            w->wsplit = (unsigned short*)need(dev_alloc<unsigned short>(t, wn * 2));
+        }
+    t->tail_fwd.KH = t->tail_fwd.KW = 3; t->tail_fwd.Cin = F; t->tail_fwd.Cout = 1; t->tail_fwd.CoutPad = 64; t->tail_fwd.ck = 32;
+    t->tail_fwd.w = (float*)need(dev_alloc<float>(t, (size_t)9 * F * 64));
+    t->tail_fwd.wsplit = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)9 * F * 64 * 2));
+    t->wt_tmp = (float*)need(dev_alloc<float>(t, wn));
+    t->tail_flip = (float*)need(dev_alloc<float>(t, (size_t)9 * F));
+    t->zero_bias = (float*)need(dev_alloc<float>(t, F, true));
+    // weight-gradient operand geometry
+    t->P = S + 8;
+    const size_t K = ((size_t)B * (S + 1) + 1) * t->P;
+    // 12 tiles per split, each workgroup doing the three row shifts in turn: 40 splits = 480 workgroups = one round of the 512
+    // slots (2 per CU), 5 splits per XCD
+    t->splitK = (int)std::max<size_t>(1, std::min<size_t>(40, K / 2048));
+    if (t->splitK >= 8) t->splitK &= ~7;
+    t->Kpad = (K + (size_t)64 * t->splitK - 1) / ((size_t)64 * t->splitK) * ((size_t)64 * t->splitK);
+    t->kchunk = t->Kpad / t->splitK;
+    t->guard = ((size_t)t->P + 8 + 63) / 64 * 64;
+    t->ld = t->guard + t->Kpad + t->guard;
+    t->a_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
+    t->a_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
+    t->b_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)3 * F * t->ld, true));
+    t->b_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)3 * F * t->ld, true));
+    t->partial = (float*)need(dev_alloc<float>(t, (size_t)t->splitK * 3 * F * 3 * F));
+    t->colpart = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
+    t->ctmp = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
+    const size_t act = (size_t)B * S * S * F, pix = (size_t)B * S * S;
+    t->X.resize(n + 1); t->U.resize(n);
+    for (int i = 0; i <= n && ok; ++i) t->X[i] = (float*)need(dev_alloc<float>(t, act));
+    for (int i = 0; i < n && ok; ++i) t->U[i] = (float*)need(dev_alloc<float>(t, act));
+    t->Y = (float*)need(dev_alloc<float>(t, act));
+    t->g0 = (float*)need(dev_alloc<float>(t, act)); t->g1 = (float*)need(dev_alloc<float>(t, act)); t->g2 = (float*)need(dev_alloc<float>(t, act));
+    t->out = (float*)need(dev_alloc<float>(t, pix)); t->xt = (float*)need(dev_alloc<float>(t, pix)); t->dout = (float*)need(dev_alloc<float>(t, pix));
+    t->per = (float*)need(dev_alloc<float>(t, 2 * B));
+    t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
+    t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
+    t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));
+    t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
+    const int nchunk = (S * S + 63) / 64;
+    t->fpart = (float*)need(dev_alloc<float>(t, (size_t)B * nchunk * 2 * F));
+    t->spart = (float*)need(dev_alloc<float>(t, (size_t)B * ((S + 7) / 8) * F * 18));
+    if (!ok) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 2 per block)"); }
+    *out = t;
+    return HD_OK;
+}
+
+int hd_train_param_count(const hd_trainer* t, long long* total_floats) {
+    if (!t) return HD_EINVAL;
+    if (total_floats) *total_floats = (long long)t->nparams;
+    return (int)t->slots.size();
+}
+
+int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long* offset, long long* shape4, int* ndim) {
+    if (!t || i < 0 || i >= (int)t->slots.size()) return HD_EINVAL;
+    const auto& s = t->slots[i];
+    if (name) *name = s.name.c_str();
+    if (offset) *offset = (long long)s.off;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = s.shape[k];
+    if (ndim) *ndim = s.ndim;
+    return HD_OK;
+}
+
+}  // extern "C"
+
+// ---- one training step ---------------------------------------------------------------------------------------------
+static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st) {
+    ConvArgs a;
+    a.in0 = in; a.C0 = tr->F; a.B = tr->B; a.H = tr->S; a.W = tr->S; a.IH = tr->S; a.IW = tr->S; a.stride = 1; a.pad = 1; a.cw = w; a.out = out;
+    a.ep = ep; a.alpha = alpha; a.res = res; a.precision = HD_PREC_BF16X3;
+    return launch_conv(a, st, nullptr);
+}
+
+static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
+    const int F = tr->F, S = tr->S;
+    if (gside)
+        hipLaunchKernelGGL(wg_prep_kernel<3>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, tr->b_hi, tr->b_lo, mode, film,
+                           2 * F, colpart);
+    else
+        hipLaunchKernelGGL(wg_prep_kernel<1>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, tr->a_hi, tr->a_lo, mode, film,
+                           2 * F, colpart);
+    return check_launch("wg_prep");
+}
+
+// dW (+)= scale * wgrad(activation side already in a_*, gradient side already in b_*)
+static int wgrad(hd_trainer* tr, float scale, bool accumulate, float* dW, hipStream_t st) {
+    const int F = tr->F, Mt = F / 128, Nt = 3 * F / 128;
+    hipLaunchKernelGGL(nt_gemm_bf16x3_kernel, dim3(Mt * Nt * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
+                       tr->P, tr->kchunk, tr->splitK, Mt, Nt, F, 3 * F, tr->partial);
+    if (check_launch("nt_gemm")) return -3;
+    const size_t per = (size_t)3 * F * 3 * F;
+    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tr->partial, tr->splitK, F, scale, accumulate ? 1 : 0, dW);
+    return check_launch("wg_reduce");
+}
+
+// db (+)= scale * column sums of the [B*S][F] row partials the last G-side prep wrote (two short serial stages)
+static int colsum(hd_trainer* tr, float scale, bool accumulate, float* db, hipStream_t st) {
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((tr->F + 255) / 256, tr->B), dim3(256), 0, st, tr->colpart, tr->S, tr->F, 1.f, 0, tr->ctmp);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((tr->F + 255) / 256, 1), dim3(256), 0, st, tr->ctmp, tr->B, tr->F, scale, accumulate ? 1 : 0, db);
+    return check_launch("colsum");
+}
+
+extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float* grads, const float* x_start, const float* cond, const long long* t,
+                                      const float* noise, const float* a_t, const float* s_t, int l2, float* loss, void* stream) {
+    if (!tr || !params || !grads || !x_start || !t || !noise || !a_t || !s_t || !loss) return HD_EINVAL;
+    if ((tr->cin0 == 2) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
+    hipStream_t st = (hipStream_t)stream;
+    const int F = tr->F, S = tr->S, B = tr->B, n = tr->nres, TD = tr->tdim, HW = S * S;
+    const size_t act = (size_t)B * HW * F;
+    tr->err.clear();
+    // ---- weights: forward image, flipped-transposed image for the data gradient
+    for (int i = 0; i <= n; ++i) {
+        const float* w = params + tr->o_conv_w[i];
+        TR_TRY(launch_pack_conv(w, tr->fwd[i].w, F, F, 3, 3, F, 0, 0, st));
+        TR_TRY(launch_split_conv(tr->fwd[i].w, tr->fwd[i].wsplit, 9, F, F, 32, st));
+        tr->fwd[i].bias = const_cast<float*>(params + tr->o_conv_b[i]);
+        hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)(((size_t)9 * F * F + 255) / 256)), dim3(256), 0, st, w, F, F, tr->wt_tmp);
+        TR_TRY(check_launch("flip_weight"));
+        TR_TRY(launch_pack_conv(tr->wt_tmp, tr->bwd[i].w, F, F, 3, 3, F, 0, 0, st));
+        TR_TRY(launch_split_conv(tr->bwd[i].w, tr->bwd[i].wsplit, 9, F, F, 32, st));
+        tr->bwd[i].bias = nullptr;
+    }
+    TR_TRY(launch_pack_conv(params + tr->o_tail_w, tr->tail_fwd.w, 1, F, 3, 3, 64, 0, 0, st));
+    TR_TRY(launch_split_conv(tr->tail_fwd.w, tr->tail_fwd.wsplit, 9, F, 64, 32, st));
+    tr->tail_fwd.bias = const_cast<float*>(params + tr->o_tail_b);
+    hipLaunchKernelGGL(flip_weight_kernel, dim3((9 * F + 255) / 256), dim3(256), 0, st, params + tr->o_tail_w, 1, F, tr->tail_flip);   // -> [F][1][3][3]
+    TR_TRY(check_launch("flip_tail"));
+
+    // ---- forward (src/hicdiff.py:694-700,711-747; src/model/hicedrn_Diff.py:267-289)
+    TR_TRY(launch_q_sample(x_start, noise, a_t, s_t, tr->xt, B, S, st));
+    hipLaunchKernelGGL(sin_emb_kernel, dim3(B), dim3(256), 0, st, t, F, tr->emb);
+    TR_TRY(check_launch("sin_emb"));
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->emb, F, params + tr->o_t1w, params + tr->o_t1b, B, F, TD, 0, tr->h1pre, TD);
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->h1pre, TD, params + tr->o_t3w, params + tr->o_t3b, B, TD, TD, 2, tr->temb, TD);
+    for (int i = 0; i < n; ++i)
+        hipLaunchKernelGGL(lin_fwd_kernel, dim3((2 * F + 3) / 4), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[i], params + tr->o_mlp_b[i], B, TD, 2 * F, 1,
+                           tr->film + (size_t)i * B * 2 * F, 2 * F);
+    TR_TRY(check_launch("time/film forward"));
+    TR_TRY(launch_conv_small_cin(tr->xt, cond, params + tr->o_head_w, params + tr->o_head_b, tr->X[0], B, S, 3, tr->cin0, F, st));
+    const size_t n4 = act / 4;
+    for (int i = 0; i < n; ++i) {
+        const float* film = tr->film + (size_t)i * B * 2 * F;
+        TR_TRY(conv3(tr, tr->fwd[i], tr->X[i], tr->U[i], 0, 1.f, nullptr, st));
+        hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, 2 * F, HW, F, n4, tr->g0);
+        TR_TRY(check_launch("film_silu_fwd"));
+        TR_TRY(conv3(tr, tr->fwd[i], tr->g0, tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
+    }
+    TR_TRY(conv3(tr, tr->fwd[n], tr->X[n], tr->Y, EP_RES, 1.f, tr->X[0], st));
+    {
+        ConvArgs o;
+        o.in0 = tr->Y; o.C0 = F; o.B = B; o.H = S; o.W = S; o.IH = S; o.IW = S; o.stride = 1; o.pad = 1; o.cw = tr->tail_fwd; o.out = tr->out;
+        o.precision = HD_PREC_BF16X3;
+        TR_TRY(launch_conv(o, st, nullptr));
+    }
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, st, tr->out, noise, HW, B, l2 ? 1 : 0, tr->per, tr->dout);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, st, tr->per, B, loss, grads + tr->o_tail_b);
+    TR_TRY(check_launch("loss"));
+
+    // ---- backward
+    const int RB = 8, nrb = (S + RB - 1) / RB;
+    // tail: dW[0][ci][tap] = sum_p Y[p + tap][ci] dout[p]; db = sum dout; dY = conv(dout, flipped tail weight)
+    hipLaunchKernelGGL(small_conv_wgrad_kernel, dim3(nrb, B), dim3(256), (size_t)(RB + 2) * (S + 2) * sizeof(float), st, tr->Y, tr->dout, (const float*)nullptr, 1, S, F, RB,
+                       -1, tr->spart);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9, 1.f, 0, grads + tr->o_tail_w);
+    TR_TRY(check_launch("tail wgrad"));
+    float* dY = tr->g1;
+    TR_TRY(launch_conv_small_cin(tr->dout, nullptr, tr->tail_flip, tr->zero_bias, dY, B, S, 3, 1, F, st));
+    // body_tail: dX_n = dgrad(dY); dW = wgrad(X_n, dY); the skip r sends dY to the head output as well
+    TR_TRY(prep(tr, tr->X[n], false, 0, nullptr, nullptr, st));
+    TR_TRY(prep(tr, dY, true, 0, nullptr, tr->colpart, st));
+    TR_TRY(wgrad(tr, 1.f, false, grads + tr->o_conv_w[n], st));
+    TR_TRY(colsum(tr, 1.f, false, grads + tr->o_conv_b[n], st));
+    float* dx = tr->g2;                       // gradient w.r.t. the current block output
+    float* da = tr->g0;
+    TR_TRY(conv3(tr, tr->bwd[n], dY, dx, 0, 1.f, nullptr, st));
+    const int nchunk = (HW + 63) / 64;
+    for (int i = n - 1; i >= 0; --i) {
+        const float* film = tr->film + (size_t)i * B * 2 * F;
+        float* dW = grads + tr->o_conv_w[i];
+        float* db = grads + tr->o_conv_b[i];
+        // second use of the conv: y = 0.1 conv(a) + x
+        TR_TRY(prep(tr, tr->U[i], false, 1, film, nullptr, st));                 // a = silu(film(u)), recomputed
+        TR_TRY(prep(tr, dx, true, 0, nullptr, tr->colpart, st));
+        TR_TRY(wgrad(tr, 0.1f, false, dW, st));
+        TR_TRY(colsum(tr, 0.1f, false, db, st));
+        TR_TRY(conv3(tr, tr->bwd[i], dx, da, 0, 1.f, nullptr, st));              // dL/da / 0.1
+        hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, 2 * F, HW, F, 64, 0.1f, tr->fpart);
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((2 * F + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, 2 * F, 1.f, 0, tr->dfilm + (size_t)i * B * 2 * F);
+        TR_TRY(check_launch("film_silu_bwd"));
+        // first use: u = conv(x)
+        TR_TRY(prep(tr, tr->X[i], false, 0, nullptr, nullptr, st));
+        TR_TRY(prep(tr, da, true, 0, nullptr, tr->colpart, st));
+        TR_TRY(wgrad(tr, 1.f, true, dW, st));
+        TR_TRY(colsum(tr, 1.f, true, db, st));
+        float* nxt = (dx == tr->g2) ? tr->Y : tr->g2;                            // Y is free once its gradients are taken; g1 keeps dY
+        TR_TRY(conv3(tr, tr->bwd[i], da, nxt, EP_RES, 1.f, dx, st));            // dx_i = dgrad(du) + dx_{i+1}
+        dx = nxt;
+    }
+    // head: d(head output) = dx + dY (the skip r); dW[co][cin][tap] = sum_p in_cin[p + tap] d[p][co]
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, dY, n4, da);
+    const float* s0 = tr->cin0 == 2 ? cond : tr->xt;
+    hipLaunchKernelGGL(small_conv_wgrad_kernel, dim3(nrb, B), dim3(256), (size_t)tr->cin0 * (RB + 2) * (S + 2) * sizeof(float), st, da, s0, tr->xt, tr->cin0, S, F,
+                       RB, 1, tr->spart);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 * tr->cin0 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9 * tr->cin0, 1.f, 0, grads + tr->o_head_w);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((F + 255) / 256, B * S), dim3(256), 0, st, da, S, F, 1.f, 0, tr->colpart);
+    TR_TRY(check_launch("head wgrad"));
+    TR_TRY(colsum(tr, 1.f, false, grads + tr->o_head_b, st));
+    // FiLM projections (Linear(SiLU(temb)) per block) and the time MLP
+    for (int i = 0; i < n; ++i) {
+        const float* df = tr->dfilm + (size_t)i * B * 2 * F;
+        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, 2 * F), dim3(256), 0, st, df, 2 * F, tr->temb, TD, B, TD, 2 * F, 1, grads + tr->o_mlp_w[i],
+                           grads + tr->o_mlp_b[i]);
+        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B), dim3(256), 0, st, df, 2 * F, params + tr->o_mlp_w[i], B, TD, 2 * F, (const float*)nullptr, 0, 0,
+                           i > 0 ? 1 : 0, tr->dst, TD);
+    }
+    hipLaunchKernelGGL(dact_mul_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256)), dim3(256), 0, st, tr->dst, tr->temb, (size_t)B * TD, 1);   // d temb
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, TD), dim3(256), 0, st, tr->dst, TD, tr->h1pre, TD, B, TD, TD, 2, grads + tr->o_t3w, grads + tr->o_t3b);
+    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B), dim3(256), 0, st, tr->dst, TD, params + tr->o_t3w, B, TD, TD, tr->h1pre, TD, 2, 0, tr->dh1, TD);
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((F + 255) / 256, TD), dim3(256), 0, st, tr->dh1, TD, tr->emb, F, B, F, TD, 0, grads + tr->o_t1w, grads + tr->o_t1b);
+    TR_TRY(check_launch("time mlp backward"));
+    return HD_OK;
+}
+
+extern "C" int hd_adam_step(float* params, const float* grads, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                            float grad_scale, void* stream) {
+    if (!params || !grads || !m || !v || n < 0 || step < 1) return HD_EINVAL;
+    if (n == 0) return HD_OK;
+    const double c1 = 1.0 - std::pow((double)b1, step), c2 = 1.0 - std::pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (size_t)n, b1, b2, eps,
+                       (float)(lr / c1), (float)(1.0 / std::sqrt(c2)), grad_scale);
+    return check_launch("adam") == 0 ? HD_OK : HD_EHIP;
+}

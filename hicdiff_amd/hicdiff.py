@@ -20,12 +20,14 @@ class GaussianDiffusion(DiffusionCore):
     KIND = "uncond"
 
     def p_losses(self, x_start, t, noise=None):
-        """src/hicdiff.py:711-747 -- forward value (no autograd graph)."""
+        """src/hicdiff.py:711-747.  Train mode under autograd: loss with .backward() from the native training step; else the value."""
         if noise is None:
             noise = self.noise_source.randn(x_start.shape) if self.noise_source is not None else torch.randn_like(x_start)
         if self.self_condition:
             raise NotImplementedError("self-conditioning on the model's own x0 (src/hicdiff.py:723-727) is unused by HiCDiff; "
                                       "use hicdiff_condition for conditioning on the low-coverage tile")
+        if self._native_training():
+            return self._native_loss(x_start, None, t, noise)
         x = self.q_sample(x_start=x_start, t=t, noise=noise)
         out = self.model(x, t, None)
         return self._loss_value(out, self._target(x_start, t, noise), t)

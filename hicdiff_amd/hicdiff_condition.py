@@ -46,6 +46,8 @@ class GaussianDiffusion(DiffusionCore):
             t = torch.randint(0, self.num_timesteps, (b,), device=x_end.device).long()
         if noise is None:
             noise = self.noise_source.randn(x_end.shape) if self.noise_source is not None else torch.randn_like(x_end)
+        if self._native_training():
+            return self._native_loss(x_end, x_start if self.self_condition else None, t, noise)
         x = self.q_sample(x_start=x_end, t=t, noise=noise)
         out = self.model(x, t, x_start if self.self_condition else None)
         return self._loss_value(out, self._target(x_end, t, noise), t)

@@ -204,6 +204,39 @@ int hd_split_pieces(const float* mat, int n, const int* origins, int ntiles, int
  * the reference's cut fails for step < piece).  Only enqueues on the stream; bit-exact (a copy). */
 int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, int step, float* mat, int n, void* stream);
 
+/* ---- training step ------------------------------------------------------ */
+
+/* Native training of the hicedrn eps-network: what `loss = diffusion(x); loss.backward(); optimizer.step()` does in
+ * train.py:109-134 with torch autograd (p_losses src/hicdiff.py:711-747, src/hicdiff_condition.py:715-746; net
+ * src/model/hicedrn_Diff.py:169-289; optim.Adam(lr=2e-5) train.py:111).  The caller owns four flat fp32 device arrays
+ * (params, grads, and Adam's m, v) laid out as hd_train_param_slot describes: the reference's state_dict order, every tensor
+ * in torch layout at a 16-byte aligned offset.  UNet and SR3 nets are not covered yet (hd_train_create returns HD_EINVAL). */
+typedef struct hd_trainer hd_trainer;
+
+/* Sizes the saved activations for batches of exactly B tiles of 1xSxS (two tensors of B*S*S*256 floats per residual block). */
+int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* arch, int B, int S);
+void hd_train_destroy(hd_trainer* t);
+const char* hd_train_last_error(const hd_trainer* t);
+
+/* Number of parameter tensors; *total_floats = length of the flat arrays. */
+int hd_train_param_count(const hd_trainer* t, long long* total_floats);
+/* Slot i: state_dict key, offset in floats, shape (padded with 1s to 4 entries), rank. */
+int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long* offset, long long* shape4, int* ndim);
+
+/* x_t = a_t[b] x_start + s_t[b] noise; eps_hat = net(x_t, t, cond); loss = mean_b mean_pixels f(eps_hat - noise), f = square
+ * (l2 != 0) or abs; grads <- d loss / d params (every slot overwritten).  t: int64[B]; a_t, s_t: float[B] =
+ * sqrt_alphas_cumprod[t], sqrt_one_minus_alphas_cumprod[t] (src/hicdiff.py:694-700); cond: the low-coverage tiles iff
+ * self_condition; loss: one device float.  Only enqueues on the stream; deterministic (no atomics). */
+int hd_train_loss_backward(hd_trainer* t, const float* params, float* grads, const float* x_start, const float* cond,
+                           const long long* timesteps, const float* noise, const float* a_t, const float* s_t, int l2, float* loss,
+                           void* stream);
+
+/* torch.optim.Adam without weight decay / amsgrad over one flat array, one launch: g = grads * grad_scale (1/world after a
+ * summing all-reduce); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).
+ * step counts from 1.  No context needed. */
+int hd_adam_step(float* params, const float* grads, float* m, float* v, long long n, float lr, float b1, float b2, float eps, int step,
+                 float grad_scale, void* stream);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-launch HIP-event timing of the convolution kernels on their launch stream (process-wide;

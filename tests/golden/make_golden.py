@@ -444,7 +444,55 @@ def case_tiles():
     save("tiles", **out)
 
 
+def case_train():
+    """train.py:111,131-134 on a 2-block hicedrn (conditional and unconditional): loss = diffusion(x); loss.backward();
+    torch.optim.Adam(lr=2e-5).step().  The oracle is compared on EVERY gradient / parameter entry here; the fixture keeps the
+    inputs, the losses, and a fixed subset + norms of every tensor (the full gradients are 7 MB)."""
+    from oracle import train as OTR
+    out = {}
+    B, S, T = 3, 16, 1000
+    x0, lq = tiles(21, B, S), tiles(22, B, S)
+    for kind in ("cond", "uncond"):
+        m, cfg = build_hicedrn(kind, 2)
+        m.train()
+        d = (R1 if kind == "cond" else R0).GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        names = [k for k, _ in m.named_parameters()]
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        buf = OD.diffusion_buffers("linear", T)
+        opt = torch.optim.Adam(d.parameters(), lr=2e-5)
+        om = {k: torch.zeros_like(sd[k]) for k in names}
+        ov = {k: torch.zeros_like(sd[k]) for k in names}
+        op = {k: sd[k].clone() for k in names}
+        with torch.enable_grad():
+            for step in range(1, 4):
+                torch.manual_seed(300 + step)
+                loss = d([lq, x0] if kind == "cond" else x0)
+                loss.backward()
+                torch.manual_seed(300 + step)
+                t = torch.randint(0, T, (B,)).long()
+                eps = torch.randn_like(x0)
+                ol, og = OTR.loss_and_grads(op, cfg, buf, x0, t, eps, lq if kind == "cond" else None, "l2")
+                check(f"train {kind} step {step} loss", loss.detach(), ol, tol=1e-6)
+                for k, prm in m.named_parameters():
+                    check(f"  grad {k}", prm.grad, og[k], tol=2e-5) if step == 1 else None
+                    g = prm.grad
+                    out[f"{kind}_s{step}_grad_sample/{k}"] = OTR.sample_of(g)
+                    out[f"{kind}_s{step}_grad_norm/{k}"] = g.norm()
+                out[f"{kind}_s{step}_t"], out[f"{kind}_s{step}_eps"], out[f"{kind}_s{step}_loss"] = t, eps, loss.detach()
+                opt.step()
+                opt.zero_grad()
+                OTR.adam_step(op, og, om, ov, step)
+                worst = max(((prm.detach() - op[k]).abs().max() / prm.detach().abs().max().clamp_min(1e-12)).item() for k, prm in m.named_parameters())
+                print(f"  [train {kind} step {step}] params after Adam: oracle vs reference worst rel {worst:.3e}")
+                assert worst < 1e-6
+                for k, prm in m.named_parameters():
+                    out[f"{kind}_s{step}_param_sample/{k}"] = OTR.sample_of(prm)
+    out["x0"], out["lq"] = x0, lq
+    save("train", **out)
+
+
 CASES = {
+    "train": case_train,
     "tiles": case_tiles,
     "metrics": case_metrics,
     "inventory": case_param_inventory,
