@@ -45,7 +45,7 @@ def test_train_three_steps_golden(kind):
         loss = d.p_losses([lq, x0], t, eps) if kind == "cond" else d.p_losses(x0, t, eps)
         assert loss.requires_grad
         loss.backward()
-        assert abs(float(loss) - float(g[f"{kind}_s{step}_loss"])) <= 1e-4 * float(g[f"{kind}_s{step}_loss"])
+        assert abs(float(loss.detach()) - float(g[f"{kind}_s{step}_loss"])) <= 1e-4 * float(g[f"{kind}_s{step}_loss"])
         for k, p in d.model.named_parameters():
             ref_s, ref_n = g[f"{kind}_s{step}_grad_sample/{k}"], float(g[f"{kind}_s{step}_grad_norm/{k}"])
             got = p.grad.detach().cpu()
@@ -145,3 +145,49 @@ def test_train_errors():
     d.train()
     with pytest.raises(AssertionError):
         d(tiles(1, 2, 24).cuda())                         # wrong tile size: the reference's assert
+
+
+def test_train_cli_trains_and_writes_reference_checkpoints(tmp_path, capsys):
+    """train.py end to end (2-block hicedrn, conditional, synthetic tiles): the loss falls, bestg_/finalg_ files carry the
+    reference's names (train.py:185,189) and load into a fresh module with strict keys."""
+    import json
+    import train
+    best = train.main(["-u", "", "-b", "4", "-e", "4", "--resnet-blocks", "2", "--tile", "16", "--tiles-per-epoch", "16", "--lr", "5e-4",
+                       "--weights-dir", str(tmp_path)])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert [l["Epoch"] for l in lines] == [1, 2, 3, 4]
+    assert lines[-1]["train/loss"] < 0.8 * lines[0]["train/loss"] and best == min(l["valid/loss"] for l in lines)
+    names = sorted(p.name for p in tmp_path.iterdir())
+    assert names == ["bestg_40000_c64_s16_Human1_HiCedrn_cond_l2_lin.pytorch", "finalg_40000_c64_s16_Human1_HiCedrn_cond_l2_lin.pytorch"]
+    from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+    from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
+    d = GaussianDiffusion(hicedrn_Diff(number_resnet=2, self_condition=True), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear")
+    d.load_state_dict(torch.load(tmp_path / names[1], map_location="cpu"))          # strict
+
+
+def test_train_two_ranks_stay_in_sync(tmp_path):
+    """The N-rank path on the one GPU of the box (gloo, both ranks on device 0): ranks draw different batches, timesteps and
+    noise, all-reduce the flat gradient once per step, and must hold identical parameters at the end."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HICDIFF_DEVICE="0", HICDIFF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+           os.path.join(root, "train.py"), "-u", "", "-b", "4", "-e", "2", "--resnet-blocks", "1", "--tile", "16", "--tiles-per-epoch", "16",
+           "--lr", "5e-4", "--weights-dir", str(tmp_path), "--print-checksum"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    sums = {}
+    for l in out.stdout.splitlines():
+        if l.startswith("{") and "param_sum" in l:
+            j = json.loads(l)
+            sums[j["rank"]] = (j["param_sum"], j["param_abs_sum"])
+    assert set(sums) == {0, 1} and sums[0] == sums[1]
+    single = subprocess.run([sys.executable, os.path.join(root, "train.py"), "-u", "", "-b", "4", "-e", "2", "--resnet-blocks", "1", "--tile", "16",
+                             "--tiles-per-epoch", "16", "--lr", "5e-4", "--weights-dir", str(tmp_path / "one"), "--print-checksum"],
+                            env=env, capture_output=True, text=True, timeout=600)
+    assert single.returncode == 0, single.stderr[-2000:]
+    one = [json.loads(l) for l in single.stdout.splitlines() if "param_sum" in l][0]
+    assert (one["param_sum"], one["param_abs_sum"]) != sums[0]            # the two-rank run really averaged different gradients

@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
 """Training driver with the reference's command line (``train.py`` :28-42) on the MI355X engine.
 
-Scope note: the hot path built so far is sampling.  The engine evaluates the
-training objective ``GaussianDiffusion.forward`` (t ~ U{0..T-1}, q_sample, epsilon-network, l1|l2 loss;
-src/hicdiff.py:711-755) but has no backward kernels yet, so this driver runs the reference's epoch
-loop as a LOSS-EVALUATION loop over synthetic tiles (train and validation splits), logs
-``Epoch / train/loss / valid/loss`` as JSON lines (the reference logs the same keys to wandb,
-train.py:187) and writes the checkpoint under the reference's file name.  ``--optimize`` (the Adam step of
-train.py:133-135) raises until the backward path exists.
+The reference's loop (train.py:109-190): Adam(lr=2e-5) over ``diffusion.parameters()``; per batch
+``loss = diffusion(x); loss.backward(); optimizer.step(); optimizer.zero_grad()``; per epoch a validation pass under
+``no_grad``, ``bestg_*.pytorch`` on a new best validation loss, ``finalg_*.pytorch`` at the end, ``Epoch / train/loss /
+valid/loss`` logged (to wandb upstream, as JSON lines here).
+
+hicedrn (the network upstream trains, conditional and unconditional) runs the NATIVE step: forward, backward and Adam are HIP
+kernels (include/hicdiff_hip.h "training step"); under torchrun every rank takes its own batches and the flat gradient is
+all-reduced once per step (RCCL).  The UNet has no backward kernels yet: ``--arch unet`` evaluates the objective only (loss curves
+of a frozen net) unless ``--optimize`` is given, which then raises.
+
+Data: ``--data-root`` points at the directory that holds ``DataFull/`` (Splits written by hicdiff_amd.processdata or by the
+reference); without it, synthetic Hi-C-like tiles.
 """
 import argparse
 import json
@@ -21,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 
 def create_parser():
-    p = argparse.ArgumentParser(description="HiCDiff training objective on MI355X")
+    p = argparse.ArgumentParser(description="HiCDiff training on MI355X")
     p.add_argument("-u", "--unspervised", type=bool, default=True)       # reference semantics: '' -> conditional
     p.add_argument("-b", "--batch_size", type=int, default=64)
     p.add_argument("-e", "--epoch", type=int, default=400)
@@ -31,55 +36,119 @@ def create_parser():
     p.add_argument("--arch", choices=["hicedrn", "unet"], default="hicedrn")
     p.add_argument("--resnet-blocks", type=int, default=32)
     p.add_argument("--tile", type=int, default=64)
-    p.add_argument("--tiles-per-epoch", type=int, default=256)
-    p.add_argument("--optimize", action="store_true", help="run the Adam step (needs backward kernels: not built yet)")
+    p.add_argument("--tiles-per-epoch", type=int, default=256, help="synthetic tiles per epoch and split when no --data-root is given")
+    p.add_argument("--data-root", default=None, help="directory holding DataFull/DataFull_<cell>_cell<n>_40000_deno_<sigma>/Splits")
+    p.add_argument("--lr", type=float, default=2e-5)
+    p.add_argument("--optimize", action="store_true", help="insist on the optimiser step (default for hicedrn; raises for the UNet)")
+    p.add_argument("--eval-only", action="store_true", help="loss curves of the frozen network, no optimiser step")
     p.add_argument("--weights-dir", default=os.path.join(ROOT, "Model_Weights"))
     p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--print-checksum", action="store_true", help="every rank prints the sum and absolute sum of its parameters at the end")
     return p
+
+
+def _batches(args, epoch, split, rank, world, device):
+    """Yield (data, target) batches of exactly batch_size tiles; ranks take disjoint batches."""
+    bs = args.batch_size
+    if args.data_root:
+        from hicdiff_amd.processdata import GSE130711Module, GSE131811Module
+        cls = GSE130711Module if args.celline == "Human" else GSE131811Module
+        dm = cls(batch_size=bs, res=40000, piece_size=args.tile, cell_line=args.celline, cell_No=args.celln, sigma_0=args.sigma, root=args.data_root)
+        dm.prepare_data()
+        dm.setup("fit")
+        ds = dm.train_set if split == "train" else dm.val_set
+        g = torch.Generator().manual_seed(args.seed + epoch)
+        order = torch.randperm(len(ds), generator=g) if split == "train" else torch.arange(len(ds))
+        lq, hq = ds.data[order], ds.target[order]
+    else:
+        from inference import synthetic_tiles
+        lq, hq = synthetic_tiles(args.tiles_per_epoch, args.tile, args.sigma, args.seed + 2 * epoch + (split != "train"))
+    nb = lq.shape[0] // bs                                               # the native trainer is sized for full batches; the ragged tail is dropped
+    for i in range(rank, nb, world):
+        yield lq[i * bs:(i + 1) * bs].to(device), hq[i * bs:(i + 1) * bs].to(device)
 
 
 def main(argv=None):
     args = create_parser().parse_args(argv)
-    if args.optimize:
-        raise NotImplementedError("the optimiser step needs the backward kernels (SURVEY.md section 8 row f-2); "
-                                  "this build evaluates the training objective only")
     conditional = not args.unspervised
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
-    torch.manual_seed(args.seed)
-    from inference import synthetic_tiles
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    torch.manual_seed(args.seed)                                         # same initial weights on every rank
     if args.arch == "hicedrn":
         from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
         net = hicedrn_Diff(number_resnet=args.resnet_blocks, self_condition=conditional)
     else:
         from hicdiff_amd.hicdiff import Unet
         net = Unet(64, dim_mults=(1, 2, 4, 8), self_condition=conditional)
+    optimise = not args.eval_only and (args.arch == "hicedrn" or args.optimize)
+    if optimise and not getattr(net, "_native_train", False):
+        raise NotImplementedError("the optimiser step needs backward kernels, built for hicedrn only so far (SURVEY.md section 8 row f-2); "
+                                  "run --arch unet without --optimize to evaluate the objective")
+    # HICDIFF_DEVICE / HICDIFF_DIST_BACKEND: rehearsal of the N-rank path on a one-GPU box (every rank on device 0, gloo)
+    device = torch.device("cuda", int(os.environ.get("HICDIFF_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("HICDIFF_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": device} if backend == "nccl" else {}))
     if conditional:
         from hicdiff_amd.hicdiff_condition import GaussianDiffusion
     else:
         from hicdiff_amd.hicdiff import GaussianDiffusion
+    from hicdiff_amd.optim import Adam
     # train.py:86-107: 1000 steps, linear schedule, l2
     diffusion = GaussianDiffusion(net, image_size=args.tile, timesteps=1000, loss_type="l2", beta_schedule="linear").to(device)
+    optimizer = Adam(diffusion.parameters(), lr=args.lr)                 # train.py:111
+    torch.manual_seed(args.seed + 1000 * (rank + 1))                     # timesteps and noise differ per rank
     best = float("inf")
     os.makedirs(args.weights_dir, exist_ok=True)
     tag = "HiCedrn" if args.arch == "hicedrn" else "Unet"
-    name = f"bestg_40000_c64_s{args.tile}_{args.celline}{args.celln}_{tag}{'_cond' if conditional else ''}_l2_lin.pytorch"
-    for epoch in range(args.epoch):
-        sums = {}
-        for split, seed in (("train", args.seed + 2 * epoch), ("valid", args.seed + 2 * epoch + 1)):
-            lq, hq = synthetic_tiles(args.tiles_per_epoch, args.tile, args.sigma, seed)
-            tot, nb = 0.0, 0
-            for b0 in range(0, lq.shape[0], args.batch_size):
-                data, target = lq[b0:b0 + args.batch_size].to(device), hq[b0:b0 + args.batch_size].to(device)
-                x = [data, target] if conditional else target          # train.py:127-130
+    stem = f"g_40000_c64_s{args.tile}_{args.celline}{args.celln}_{tag}{'_cond' if conditional else ''}_l2_lin.pytorch"
+
+    def mean_over_ranks(total, count):
+        if dist is not None:
+            v = torch.tensor([total, count], dtype=torch.float64, device=device)
+            dist.all_reduce(v)
+            total, count = float(v[0]), float(v[1])
+        return total / max(count, 1.0)
+
+    for epoch in range(1, args.epoch + 1):
+        diffusion.train()
+        tot, n = 0.0, 0
+        for data, target in _batches(args, epoch, "train", rank, world, device):
+            x = [data, target] if conditional else target               # train.py:127-130
+            if optimise:
+                loss = diffusion(x)
+                loss.backward()
+                optimizer.step()
+                optimizer.zero_grad()
+            else:
                 with torch.no_grad():
-                    tot += float(diffusion(x))
-                nb += 1
-            sums[split] = tot / max(nb, 1)
-        print(json.dumps({"Epoch": epoch, "train/loss": sums["train"], "valid/loss": sums["valid"]}), flush=True)
-        if sums["valid"] < best:                                       # train.py:182-186
-            best = sums["valid"]
-            torch.save(diffusion.state_dict(), os.path.join(args.weights_dir, name))
+                    loss = diffusion(x)
+            tot += float(loss.detach()) * data.shape[0]
+            n += data.shape[0]
+        train_loss = mean_over_ranks(tot, n)
+        diffusion.eval()
+        tot, n = 0.0, 0
+        with torch.no_grad():
+            for data, target in _batches(args, epoch, "valid", rank, world, device):
+                tot += float(diffusion([data, target] if conditional else target)) * data.shape[0]
+                n += data.shape[0]
+        valid_loss = mean_over_ranks(tot, n)
+        if rank == 0:
+            print(json.dumps({"Epoch": epoch, "train/loss": train_loss, "valid/loss": valid_loss}), flush=True)
+            if valid_loss < best:                                        # train.py:182-186
+                best = valid_loss
+                torch.save(diffusion.state_dict(), os.path.join(args.weights_dir, "best" + stem))
+    if rank == 0:
+        torch.save(diffusion.state_dict(), os.path.join(args.weights_dir, "final" + stem))      # train.py:189-190
+    if args.print_checksum:
+        flat = torch.cat([p.detach().reshape(-1).double() for p in diffusion.parameters()])
+        print(json.dumps({"rank": rank, "param_sum": float(flat.sum()), "param_abs_sum": float(flat.abs().sum())}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
     return best
 
 
