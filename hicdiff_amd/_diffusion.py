@@ -350,7 +350,9 @@ class DiffusionCore(nn.Module):
             raise NotImplementedError("the reference trains with objective='pred_noise' only")
         if self.loss_type not in ("l1", "l2"):
             raise ValueError(f"invalid loss type {self.loss_type}")
-        if float(self.p2_loss_weight.min()) != 1.0 or float(self.p2_loss_weight.max()) != 1.0:
+        if self.__dict__.get("_p2_is_one") is None:                      # checked once: it costs a device -> host read
+            self.__dict__["_p2_is_one"] = float(self.p2_loss_weight.min()) == 1.0 and float(self.p2_loss_weight.max()) == 1.0
+        if not self.__dict__["_p2_is_one"]:
             raise NotImplementedError("p2_loss_weight_gamma != 0 is not used by the reference's training")
         tr = trainer_for(self.model, x_start.shape[0], x_start.shape[-1])
         a_t = self.sqrt_alphas_cumprod.gather(-1, t)

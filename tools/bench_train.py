@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cond", type=int, default=1)
+    ap.add_argument("--cpu-baseline", type=int, default=0, help="tiles for a bounded CPU leg (oracle autograd + Adam restatement, torch CPU fp32); 0 = skip")
     a = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -72,6 +73,22 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     losses.append(float(last.detach()))
+    cpu = None
+    if rank == 0 and a.cpu_baseline > 0:
+        from oracle import diffusion as OD, nets as ON, train as OTR
+        n = a.cpu_baseline
+        sd = {k: v.detach().cpu().clone() for k, v in d.model.state_dict().items()}
+        cfg = ON.HicedrnCfg(number_resnet=a.blocks, self_condition=bool(a.cond), sr3=False)
+        buf = OD.diffusion_buffers("linear", 1000)
+        m, v = {k: torch.zeros_like(p) for k, p in sd.items()}, {k: torch.zeros_like(p) for k, p in sd.items()}
+        tt = torch.randint(0, 1000, (n,))
+        ee = torch.randn((n, 1, a.tile, a.tile))
+        c0 = time.perf_counter()
+        _, gr = OTR.loss_and_grads(sd, cfg, buf, hq[:n].cpu(), tt, ee, lq[:n].cpu() if a.cond else None, "l2")
+        OTR.adam_step(sd, gr, m, v, 1)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(n / cdt, 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one training step (autograd forward + backward + Adam) of the same net on {n} tiles, torch CPU fp32 oracle"}
     if rank == 0:
         ms = dt / a.steps * 1e3
         flop_tile = 2 * 9 * 256 * 256 * a.tile * a.tile * (2 * a.blocks + 1) * 3        # fwd + dgrad + wgrad of the 256->256 convs
@@ -79,7 +96,7 @@ def main():
                           "n_gpus": world, "ms_per_step": round(ms, 2), "steps": a.steps, "warmup": a.warmup,
                           "config": {"workload": f"hicedrn x{a.blocks} blocks, {'conditional' if a.cond else 'unconditional'}, {a.batch} tiles of 1x{a.tile}x{a.tile} per GPU"},
                           "algorithmic_TFLOPs": round(flop_tile * a.batch / (ms / 1e3) / 1e12, 1), "dtype": "f32 master, split-bf16 x3 MFMA products",
-                          "loss_first_last": [losses[0], losses[-1]]}))
+                          "loss_first_last": [losses[0], losses[-1]], "cpu_baseline": cpu}))
     if world > 1:
         dist.destroy_process_group()
 
