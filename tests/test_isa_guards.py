@@ -50,3 +50,26 @@ def test_conv_kernels_have_no_scratch_and_no_odd_register_broadcast(src):
         if any(a == 1 and b == 1 for a, b in zip(sel, sel_hi)):      # lane 0 AND lane 1 of that operand read the odd register
             bad.append(line)
     assert not bad, "packed fp32 ops broadcasting from the odd register of a pair:\n" + "\n".join(bad[:8])
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
+    """train.hip: with the prefetch registers in an indexed array hipcc parked them in scratch and waited after every load
+    (8.4 ms per GEMM instead of 1.8).  The GEMM must have no scratch and must issue its 16 loads of a slice back to back."""
+    text = _asm("train.hip")
+    kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S))
+    name = next(k for k in kernels if "nt_gemm_bf16x3_kernel" in k)
+    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", kernels[name]).group(1)) == 0
+    body = text[text.index(name + ":"):]
+    body = body[:body.index("s_endpgm")]
+    assert "scratch_" not in body
+    ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
+    runs, cur = [], 0
+    for op in ops:
+        if op.startswith("global_load_dwordx4"):
+            cur += 1
+        elif op.startswith("s_waitcnt") or op.startswith("scratch"):
+            runs.append(cur)
+            cur = 0
+    runs.append(cur)
+    assert max(runs) >= 16, f"longest run of global loads without a wait: {max(runs)}"
