@@ -2,6 +2,8 @@
 """Headline benchmark: denoised Hi-C tiles / second for a 1000-step reverse (ancestral DDPM) chain.
 
     python bench.py [--gpus N --steps K --warmup W] [--workload unet64|unet40|hicedrn64|unet64cond]
+    python bench.py --workload hicedrn64_train [--batch 64 --steps 5 --warmup 2]     (native training step)
+    python bench.py --workload tiles                                                (tile producer / stitcher, section 8 f-3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -114,15 +116,168 @@ def cpu_baseline(w, budget_s=20.0):
     }
 
 
+def bench_train(args):
+    """--workload hicedrn64_train: training tiles / second of the native hicedrn step.
+    A step = `loss = diffusion([lq, hq]); loss.backward(); optimizer.step(); optimizer.zero_grad()` (train.py:120-134) on synthetic
+    tiles resident in HBM; data parallel under torchrun (one all-reduce of the flat gradient per step), weak scaling."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+    from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
+    from hicdiff_amd.optim import Adam
+    batch, tile, blocks = args.batch or 64, args.tile or 64, args.blocks
+    torch.manual_seed(1234)
+    d = GaussianDiffusion(hicedrn_Diff(number_resnet=blocks, self_condition=True), image_size=tile, timesteps=1000, loss_type="l2",
+                          beta_schedule="linear").to(dev)
+    d.train()
+    opt = Adam(d.parameters(), lr=2e-5)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    hq = torch.rand((batch, 1, tile, tile), device=dev, generator=g) * 2 - 1
+    lq = (hq + 0.1 * torch.randn(hq.shape, device=dev, generator=g)).clamp(-1, 1)
+
+    def step():
+        loss = d([lq, hq])
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+
+    first = None
+    for _ in range(max(args.warmup, 1)):
+        v = float(step().detach())
+        first = v if first is None else first
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import diffusion as OD, nets as ON, train as OTR
+        n = 2
+        sd = {k: v.detach().cpu().clone() for k, v in d.model.state_dict().items()}
+        cfg = ON.HicedrnCfg(number_resnet=blocks, self_condition=True, sr3=False)
+        buf = OD.diffusion_buffers("linear", 1000)
+        m, v = {k: torch.zeros_like(p) for k, p in sd.items()}, {k: torch.zeros_like(p) for k, p in sd.items()}
+        c0 = time.perf_counter()
+        _, gr = OTR.loss_and_grads(sd, cfg, buf, hq[:n].cpu(), torch.randint(0, 1000, (n,)), torch.randn((n, 1, tile, tile)), lq[:n].cpu(), "l2")
+        OTR.adam_step(sd, gr, m, v, 1)
+        cpu = {"value": round(n / (time.perf_counter() - c0), 3), "unit": "tiles/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"one training step (autograd forward + backward + Adam) of the same net on {n} tiles, torch CPU fp32 oracle"}
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        flop_tile = 2 * 9 * 256 * 256 * tile * tile * (2 * blocks + 1) * 3        # forward + data gradient + weight gradient of the 256->256 convs
+        achieved = flop_tile * batch / (ms / 1e3) / 1e12
+        print(json.dumps({
+            "metric": "training tiles/sec (hicedrn, l2, Adam)", "value": round(batch * world / (ms / 1e3), 2), "unit": "tiles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 master weights and gradients; products split-bf16 x3 MFMA, fp32 accumulate", "data": "synthetic",
+            "config": {"workload": f"hicedrn64_train: hicedrn x{blocks} blocks, conditional, {batch} tiles of 1x{tile}x{tile} per GPU, Adam lr 2e-5",
+                       "tiles_per_gpu": batch, "tile": tile, "parallelism": f"data-parallel x{world}, one flat-gradient all-reduce per step"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": round(PEAK_BF16_MFMA_TFLOPS / 3, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / (PEAK_BF16_MFMA_TFLOPS / 3), 4), "traffic": None,
+                         "note": "whole step: algorithmic flops of the 256->256 convolutions (forward, data gradient, weight gradient) over the step time; "
+                                 "per-kernel durations in profiles/r01_h_train_hicedrn64_b64_kernel_stats.csv"},
+            "cpu_baseline": cpu, "loss_first_last": [first, float(last.detach())]}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def bench_tiles(args):
+    """--workload tiles: the tile producer / stitcher on one chromosome-sized matrix (chr1 at 10 kb).
+    Algorithmic bytes: split reads and writes every tile element once (2 * ntiles * piece^2 * 4 B); stitch reads every tile once and
+    writes the whole n x n matrix.  Kernels timed with HIP events on the launch stream, operands and tables resident in HBM."""
+    import ctypes as C
+
+    import numpy as np
+    from hicdiff_amd import _lib as L
+    from hicdiff_amd import processdata as PD
+    from hicdiff_amd.processdata.PrepareData_linear_sing import stitch_table
+    n, piece, res, reps = args.matrix_size, args.tile or 64, args.res, max(args.steps, 1)
+    dev = torch.device("cuda:0")
+    m = torch.rand((n, n), device=dev)
+    m = (m + m.T) / 2
+    tiles, org = PD.split_pieces_device(m, piece, piece, res)
+    back = PD.stitch_pieces_device(tiles, org, n)
+    torch.cuda.synchronize()
+
+    def timed(fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    lib = L.load()
+    o_dev = torch.from_numpy(org.astype(np.int32)).to(dev)
+    tb = stitch_table(org, n, piece)
+    t_dev = torch.from_numpy(tb).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    P = lambda x: C.c_void_p(x.data_ptr())
+    ms_split = timed(lambda: lib.hd_split_pieces(P(m), n, P(o_dev), len(org), piece, P(tiles), st))
+    ms_stitch = timed(lambda: lib.hd_stitch_pieces(P(tiles), P(t_dev), tb.shape[0], piece, piece, P(back), n, st))
+    ms_api = timed(lambda: PD.split_pieces_device(m, piece, piece, res))
+    nt, pp = len(org), piece * piece
+    b_split, b_stitch = 2 * nt * pp * 4, nt * pp * 4 + n * n * 4
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import tiles as OT
+        ncpu = min(n, 6000)
+        mc = m[:ncpu, :ncpu].cpu().numpy()
+        t0 = time.perf_counter()
+        ref = OT.split_pieces(mc, piece, piece, res)
+        cpu = {"value": round(len(ref) / (time.perf_counter() - t0)), "unit": "tiles/s", "cores": 1, "kind": "port",
+               "sample": f"numpy slicing (as the reference does) of the leading {ncpu}x{ncpu} block: {len(ref)} tiles"}
+    print(json.dumps({
+        "metric": "tiles cut / second (splitPieces)", "value": round(nt / ms_split * 1e3), "unit": "tiles/s", "n_gpus": 1, "steps": reps, "warmup": 1,
+        "ms_per_step": round(ms_split, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"tiles: n={n} piece={piece} res={res}: {nt} tiles"},
+        "roofline": {"bound": "hbm", "achieved": round(b_split / ms_split / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": round(b_split / ms_split / 1e6 / PEAK_HBM_GBS, 3), "traffic": None, "kernel": "split_pieces_kernel<true>"},
+        "stitch": {"ms": round(ms_stitch, 4), "GBps": round(b_stitch / ms_stitch / 1e6, 1), "frac_hbm": round(b_stitch / ms_stitch / 1e6 / PEAK_HBM_GBS, 3),
+                   "kernel": "stitch_pieces_vec4_kernel"},
+        "split_ms_with_host_tables": round(ms_api, 4), "cpu_baseline": cpu,
+        "round_trip_exact": bool(torch.equal(PD.split_pieces_device(back, piece, piece, res)[0], tiles))}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="unet64", choices=sorted(WORK))
+    ap.add_argument("--workload", default="unet64", choices=sorted(WORK) + ["hicedrn64_train", "tiles"])
+    ap.add_argument("--tile", type=int, default=None, help="hicedrn64_train / tiles: tile size (default 64)")
+    ap.add_argument("--blocks", type=int, default=32, help="hicedrn64_train: residual blocks")
+    ap.add_argument("--matrix-size", type=int, default=24896, help="tiles: matrix side (chr1 at 10 kb)")
+    ap.add_argument("--res", type=int, default=10000, help="tiles: bin size")
     ap.add_argument("--batch", type=int, default=None, help="tiles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.workload == "hicedrn64_train":
+        return bench_train(args)
+    if args.workload == "tiles":
+        return bench_tiles(args)
 
     w = dict(WORK[args.workload])
     if args.batch:
