@@ -273,6 +273,7 @@ def main():
     ap.add_argument("--res", type=int, default=10000, help="tiles: bin size")
     ap.add_argument("--batch", type=int, default=None, help="tiles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
     args = ap.parse_args()
     if args.workload == "hicedrn64_train":
         return bench_train(args)
@@ -334,6 +335,11 @@ def main():
     n_rows = lib.hd_profile_read(rows_buf, L.HD_PROFILE_MAX_ROWS)
     rows = [rows_buf[i] for i in range(max(n_rows, 0))]
     lib.hd_profile_enable(0)
+    if args.kernel_table and rank == 0:
+        for r in sorted(rows, key=lambda r: -r.total_ms):
+            ms = r.total_ms / prof_steps
+            print(f"{r.kernel.decode():58s} {r.launches // prof_steps:4d}/step {ms:7.3f} ms/step {r.flops / r.total_ms / 1e9:7.1f} TFLOP/s-eq "
+                  f"{r.bytes / r.total_ms / 1e6:7.0f} GB/s", file=sys.stderr)
 
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if dist is not None:

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -31,140 +32,175 @@ int check_launch(const char* what) {
 }
 
 // ---- weight-gradient operands ---------------------------------------------------------------------------------------
-// in: NHWC fp32 [B][H][W][C].  out: bf16 hi / lo images [NSHIFT*C][ld]; pixel (b,y,x) of channel c lands at
-// k = guard + (b*(H+1) + y + 1) * P + 8 + x (+ dx for copy dx+1 of NSHIFT == 3).  Pad positions are never written: the
-// buffers are zeroed once.  mode 1 applies the block's FiLM + SiLU on the way in (the activation between the two uses of
-// the block's convolution is recomputed instead of stored).  colpart (optional): per-row channel sums for the bias gradient.
-template <int NSHIFT>
+// in: NHWC fp32 [B][H][W][C], C <= 256, W <= 64, W % 8 == 0.  out: bf16 hi / lo images [C][ld]; pixel (b,y,x) of channel c
+// lands at k = guard + (b*(H+1) + y + 1) * P + 8 + x.  Pad positions are never written: the buffers are zeroed once.
+// mode 1 applies the block's FiLM + SiLU on the way in (the activation between the two uses of the block's convolution is
+// recomputed instead of stored).  colpart (optional): per-row channel sums for the bias gradient.
+// One workgroup per image row: float4 loads of four channels per thread on the way in, LDS transpose, then 16-byte stores of
+// 8 pixels per lane on the way out (8 lanes cover a channel's 64-pixel row segment).
 __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
                                                       const float* __restrict__ film, int film_bs, float* __restrict__ colpart) {
-    // pixel-major [x][C+2] ushorts: the channel-per-thread writes and the pixel-per-lane reads are both conflict-free
-    __shared__ unsigned short sh_hi[64 * 258], sh_lo[64 * 258];
-    const int Cp = C + 2;
+    constexpr int PITCH = 68;                                  // ushorts per channel row: 136 B, 8-byte aligned, 2-way conflicts at most
+    __shared__ __attribute__((aligned(16))) unsigned short sh_hi[256 * PITCH], sh_lo[256 * PITCH];
+    __shared__ float csum[4][256];
     const int b = blockIdx.x / H, y = blockIdx.x % H, tid = threadIdx.x;
-    for (int c = tid; c < C; c += 256) {
-        float sc = 0.f, shf = 0.f, sum = 0.f;
-        if (mode == 1) { sc = film[(size_t)b * film_bs + c] + 1.f; shf = film[(size_t)b * film_bs + C + c]; }
-        const float* src = in + ((size_t)(b * H + y) * W) * C + c;
-        for (int x = 0; x < W; ++x) {
-            float v = src[(size_t)x * C];
-            if (mode == 1) v = silu_f(v * sc + shf);
-            sum += v;
-            const __bf16 hh = (__bf16)v;
-            const __bf16 ll = (__bf16)(v - (float)hh);
-            sh_hi[x * Cp + c] = __builtin_bit_cast(unsigned short, hh);
-            sh_lo[x * Cp + c] = __builtin_bit_cast(unsigned short, ll);
+    // thread = (channel quad, pixel group): float4 loads (1 KB per wave), pixels pg, pg + 4, ...
+    const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4;
+    if (c0 < C) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mode == 1) {
+            sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c0);
+            sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
+            shf = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + C + c0);
         }
-        if (colpart) colpart[(size_t)blockIdx.x * C + c] = sum;
+        const float* src = in + ((size_t)(b * H + y) * W) * C + c0;
+        for (int x = pgp; x < W; x += 4) {
+            float4 v = *reinterpret_cast<const float4*>(src + (size_t)x * C);
+            if (mode == 1) { v.x = silu_f(v.x * sc.x + shf.x); v.y = silu_f(v.y * sc.y + shf.y); v.z = silu_f(v.z * sc.z + shf.z); v.w = silu_f(v.w * sc.w + shf.w); }
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const __bf16 hh = (__bf16)e[j];
+                const __bf16 ll = (__bf16)(e[j] - (float)hh);
+                sh_hi[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, hh);
+                sh_lo[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, ll);
+            }
+        }
+        csum[pgp][c0] = sum.x; csum[pgp][c0 + 1] = sum.y; csum[pgp][c0 + 2] = sum.z; csum[pgp][c0 + 3] = sum.w;
     }
     __syncthreads();
-    const int lane = tid & 63, w = tid >> 6;
-    const size_t kbase = guard + ((size_t)b * (H + 1) + y + 1) * P + 8;
-    if (lane < W) {
-        for (int c = w; c < C; c += 4) {
-            const unsigned short vh = sh_hi[lane * Cp + c], vl = sh_lo[lane * Cp + c];
-#pragma unroll
-            for (int s = 0; s < NSHIFT; ++s) {
-                const int dx = NSHIFT == 3 ? s - 1 : 0;
-                const size_t o = ((size_t)s * C + c) * ld + kbase + lane + dx;
-                hi[o] = vh; lo[o] = vl;
-            }
+    if (colpart && tid < C) colpart[(size_t)blockIdx.x * C + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+    const int xg = tid & 7;
+    const size_t kbase = guard + ((size_t)b * (H + 1) + y + 1) * P + 8 + xg * 8;
+    if (xg * 8 < W) {
+        for (int c = tid >> 3; c < C; c += 32) {
+            const uint2* ph = reinterpret_cast<const uint2*>(sh_hi + c * PITCH + xg * 8);
+            const uint2* pl = reinterpret_cast<const uint2*>(sh_lo + c * PITCH + xg * 8);
+            const uint2 h0 = ph[0], h1 = ph[1], l0 = pl[0], l1 = pl[1];
+            *reinterpret_cast<uint4*>(hi + (size_t)c * ld + kbase) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            *reinterpret_cast<uint4*>(lo + (size_t)c * ld + kbase) = make_uint4(l0.x, l0.y, l1.x, l1.y);
         }
     }
 }
 
-// partial[(split*3 + dyi)][M][N] = sum over this split's k of A[m][k + (dyi-1)*P] * B[n][k], split-bf16 x3.
-// 128x128 tile per workgroup, 4 waves as 2x2 of 64x64, K slices of 64 staged through LDS (row pitch 144 B: the 16-byte
-// operand reads of 16 consecutive rows fall in distinct banks), next slice prefetched into registers under the MFMAs.
-__global__ __launch_bounds__(256, 2) void nt_gemm_bf16x3_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
-                                                             const unsigned short* __restrict__ Bhi, const unsigned short* __restrict__ Blo,
-                                                             size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int N,
-                                                             float* __restrict__ partial) {
-    constexpr int BM = 128, KS = 64, PITCH = KS * 2 + 16;
-    __shared__ __attribute__((aligned(16))) char sm[4][BM * PITCH];
+// Weight-gradient GEMM, split-bf16 x3: partial[(split*3 + dyi)][ci][kx*F + co] = sum over this split's k of
+// A[ci][k + (dyi-1)*P] * G[co][k - (kx-1)].  The three column taps are built in registers from one LDS image of G: a 16-byte operand (8 bf16 along k) shifted by one element is four v_alignbit over the aligned
+// operand and one neighbouring dword.  Workgroup tile: 128 input channels x 64 output channels x 3 column taps; 4 waves as
+// 2 (rows) x 2 (columns), each 64 x 32 x 3 taps = 6 accumulator tiles.  Per K slice of 64 the workgroup loads 32 KB of A and
+// 20 KB of G (with an 8-element halo either side) for 72 MFMAs per wave.  The next slice is prefetched into NAMED registers under
+// the MFMAs (an indexed register array went to scratch with a wait after every load: 4.6x slower), unconditionally (the last
+// iteration re-reads its own slice).  Workgroups that stream the same k range share an XCD (blockIdx round-robins over the 8
+// XCDs), so the 8 tiles of a split re-read its operand slices from that XCD's L2.
+__device__ __forceinline__ uint4 shift_prev(const uint4& c, unsigned prevw) {          // elements k-1 .. k+6
+    return make_uint4(__builtin_amdgcn_alignbit(c.x, prevw, 16), __builtin_amdgcn_alignbit(c.y, c.x, 16),
+                      __builtin_amdgcn_alignbit(c.z, c.y, 16), __builtin_amdgcn_alignbit(c.w, c.z, 16));
+}
+__device__ __forceinline__ uint4 shift_next(const uint4& c, unsigned nextx) {          // elements k+1 .. k+8
+    return make_uint4(__builtin_amdgcn_alignbit(c.y, c.x, 16), __builtin_amdgcn_alignbit(c.z, c.y, 16),
+                      __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(nextx, c.w, 16));
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
+                                                            const unsigned short* __restrict__ Ghi, const unsigned short* __restrict__ Glo,
+                                                            size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int F,
+                                                            float* __restrict__ partial, int xcd_group) {
+    constexpr int BM = 128, BN = 64, KS = 64, PA = KS * 2 + 16, PG = (KS + 16) * 2 + 16;      // 144, 176 bytes
+    __shared__ __attribute__((aligned(16))) char sA[2][BM * PA];
+    __shared__ __attribute__((aligned(16))) char sG[2][BN * PG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
     const int wm = w >> 1, wn = w & 1;
-    // Workgroups that stream the same k range share an XCD (blockIdx round-robins over the 8 XCDs), so the 12 tiles of a split
-    // re-read its operand slices from that XCD's L2 instead of from HBM.
     const int per = Mtiles * Ntiles;
     int split, inner;
-    if ((nsplit & 7) == 0) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
+    if ((nsplit & 7) == 0 && xcd_group) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
     else { split = blockIdx.x / per; inner = blockIdx.x % per; }
     const int nt = inner % Ntiles, mt = inner / Ntiles;
     const size_t k0 = guard + (size_t)split * kchunk;
     const int nslices = (int)(kchunk / KS);
-    // this thread's four 16-byte chunks of every 128 x 64 operand slice: rows lrow + 32 j, chunk lch
+    const int N = 3 * F;
+    // A: rows lrow + 32 j (j < 4), chunk lch.  G: 64 rows x 10 chunks x {hi, lo} = 1280 chunks, five per thread.
     const int lrow = tid >> 3, lch = tid & 7;
-    const size_t goff = (size_t)lrow * ld + lch * 8;
-    const int loff = lrow * PITCH + lch * 16;
+    const size_t aoff = (size_t)lrow * ld + lch * 8;
+    const int aloff = lrow * PA + lch * 16;
+#define HD_GDEF(j)                                                                                                   \
+    const int q##j = tid + 256 * j, wh##j = q##j >= 640 ? 1 : 0, rem##j = q##j - 640 * wh##j, row##j = rem##j / 10,  \
+              ch##j = rem##j - 10 * row##j;                                                                          \
+    const unsigned short* pg##j = (wh##j ? Glo : Ghi) + (size_t)(nt * BN + row##j) * ld + (k0 - 8) + ch##j * 8;      \
+    char* const lg##j = sG[wh##j] + row##j * PG + ch##j * 16;
+    HD_GDEF(0) HD_GDEF(1) HD_GDEF(2) HD_GDEF(3) HD_GDEF(4)
+#undef HD_GDEF
     for (int dyi = 0; dyi < 3; ++dyi) {
-    const size_t ka = (size_t)((long)k0 + (long)(dyi - 1) * P);       // >= 0: guard >= P
-    const unsigned short* pAh = Ahi + (size_t)mt * BM * ld + ka + goff;
-    const unsigned short* pAl = Alo + (size_t)mt * BM * ld + ka + goff;
-    const unsigned short* pBh = Bhi + (size_t)nt * BM * ld + k0 + goff;
-    const unsigned short* pBl = Blo + (size_t)nt * BM * ld + k0 + goff;
-    // sixteen named registers, not arrays: indexed arrays of prefetch registers end up in scratch with a wait after every load
-    uint4 rAh0, rAh1, rAh2, rAh3, rAl0, rAl1, rAl2, rAl3, rBh0, rBh1, rBh2, rBh3, rBl0, rBl1, rBl2, rBl3;
+    const size_t ka = (size_t)((long)k0 + (long)(dyi - 1) * P);
+    const unsigned short* pAh = Ahi + (size_t)mt * BM * ld + ka + aoff;
+    const unsigned short* pAl = Alo + (size_t)mt * BM * ld + ka + aoff;
+    uint4 rAh0, rAh1, rAh2, rAh3, rAl0, rAl1, rAl2, rAl3, rG0, rG1, rG2, rG3, rG4;
 #define HD_LD(p, j, K) (*reinterpret_cast<const uint4*>((p) + (size_t)(j) * 32 * ld + (K)))
-#define HD_GLOAD(K)                                                                                                     \
-    rAh0 = HD_LD(pAh, 0, K); rAl0 = HD_LD(pAl, 0, K); rBh0 = HD_LD(pBh, 0, K); rBl0 = HD_LD(pBl, 0, K);                 \
-    rAh1 = HD_LD(pAh, 1, K); rAl1 = HD_LD(pAl, 1, K); rBh1 = HD_LD(pBh, 1, K); rBl1 = HD_LD(pBl, 1, K);                 \
-    rAh2 = HD_LD(pAh, 2, K); rAl2 = HD_LD(pAl, 2, K); rBh2 = HD_LD(pBh, 2, K); rBl2 = HD_LD(pBl, 2, K);                 \
-    rAh3 = HD_LD(pAh, 3, K); rAl3 = HD_LD(pAl, 3, K); rBh3 = HD_LD(pBh, 3, K); rBl3 = HD_LD(pBl, 3, K);
-#define HD_ST(m, j, r) *reinterpret_cast<uint4*>(sm[m] + loff + (j) * 32 * PITCH) = r
-    f32x16 acc[2][2];
+#define HD_LG(j, K) (*reinterpret_cast<const uint4*>(pg##j + (K)))
+#define HD_GLOAD(K)                                                                                  \
+    rAh0 = HD_LD(pAh, 0, K); rAl0 = HD_LD(pAl, 0, K); rAh1 = HD_LD(pAh, 1, K); rAl1 = HD_LD(pAl, 1, K); \
+    rAh2 = HD_LD(pAh, 2, K); rAl2 = HD_LD(pAl, 2, K); rAh3 = HD_LD(pAh, 3, K); rAl3 = HD_LD(pAl, 3, K); \
+    rG0 = HD_LG(0, K); rG1 = HD_LG(1, K); rG2 = HD_LG(2, K); rG3 = HD_LG(3, K); rG4 = HD_LG(4, K);
+#define HD_STA(m, j, r) *reinterpret_cast<uint4*>(sA[m] + aloff + (j) * 32 * PA) = r
+#define HD_STG(j, r) *reinterpret_cast<uint4*>(lg##j) = r
+    f32x16 acc[2][3];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     HD_GLOAD(0)
     for (int s = 0; s < nslices; ++s) {
-        HD_ST(0, 0, rAh0); HD_ST(0, 1, rAh1); HD_ST(0, 2, rAh2); HD_ST(0, 3, rAh3);
-        HD_ST(1, 0, rAl0); HD_ST(1, 1, rAl1); HD_ST(1, 2, rAl2); HD_ST(1, 3, rAl3);
-        HD_ST(2, 0, rBh0); HD_ST(2, 1, rBh1); HD_ST(2, 2, rBh2); HD_ST(2, 3, rBh3);
-        HD_ST(3, 0, rBl0); HD_ST(3, 1, rBl1); HD_ST(3, 2, rBl2); HD_ST(3, 3, rBl3);
+        HD_STA(0, 0, rAh0); HD_STA(0, 1, rAh1); HD_STA(0, 2, rAh2); HD_STA(0, 3, rAh3);
+        HD_STA(1, 0, rAl0); HD_STA(1, 1, rAl1); HD_STA(1, 2, rAl2); HD_STA(1, 3, rAl3);
+        HD_STG(0, rG0); HD_STG(1, rG1); HD_STG(2, rG2); HD_STG(3, rG3); HD_STG(4, rG4);
         __syncthreads();
-        // unconditional (the last iteration re-reads its own slice): a conditional prefetch sends these registers to scratch
         { const size_t kn = (size_t)min(s + 1, nslices - 1) * KS; HD_GLOAD(kn) }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 ah[2], al[2], bh[2], bl[2];
+            bf16x8 ah[2], al[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int ro = (wm * 64 + t * 32 + l31) * PITCH + ks * 32 + half * 16;
-                const int co = (wn * 64 + t * 32 + l31) * PITCH + ks * 32 + half * 16;
-                ah[t] = *reinterpret_cast<const bf16x8*>(sm[0] + ro);
-                al[t] = *reinterpret_cast<const bf16x8*>(sm[1] + ro);
-                bh[t] = *reinterpret_cast<const bf16x8*>(sm[2] + co);
-                bl[t] = *reinterpret_cast<const bf16x8*>(sm[3] + co);
+                const int ro = (wm * 64 + t * 32 + l31) * PA + ks * 32 + half * 16;
+                ah[t] = *reinterpret_cast<const bf16x8*>(sA[0] + ro);
+                al[t] = *reinterpret_cast<const bf16x8*>(sA[1] + ro);
             }
+            const int go = (wn * 32 + l31) * PG + ks * 32 + half * 16 + 16;                 // element k sits at byte (k - k0 + 8) * 2
+            const uint4 ch = *reinterpret_cast<const uint4*>(sG[0] + go), cl = *reinterpret_cast<const uint4*>(sG[1] + go);
+            const unsigned ph = *reinterpret_cast<const unsigned*>(sG[0] + go - 4), pl = *reinterpret_cast<const unsigned*>(sG[1] + go - 4);
+            const unsigned nh = *reinterpret_cast<const unsigned*>(sG[0] + go + 16), nl = *reinterpret_cast<const unsigned*>(sG[1] + go + 16);
+            bf16x8 bh[3], bl[3];
+            // kx = 0 (dx = -1): G[k + 1 ...];  kx = 1: G[k ...];  kx = 2 (dx = +1): G[k - 1 ...]
+            bh[0] = __builtin_bit_cast(bf16x8, shift_next(ch, nh)); bl[0] = __builtin_bit_cast(bf16x8, shift_next(cl, nl));
+            bh[1] = __builtin_bit_cast(bf16x8, ch);                 bl[1] = __builtin_bit_cast(bf16x8, cl);
+            bh[2] = __builtin_bit_cast(bf16x8, shift_prev(ch, ph)); bl[2] = __builtin_bit_cast(bf16x8, shift_prev(cl, pl));
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int tn = 0; tn < 2; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                for (int dx = 0; dx < 3; ++dx) {
+                    acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[dx], acc[tm][dx], 0, 0, 0);
+                    acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[dx], acc[tm][dx], 0, 0, 0);
+                    acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[dx], acc[tm][dx], 0, 0, 0);
                 }
         }
         __syncthreads();
     }
 #undef HD_GLOAD
 #undef HD_LD
-#undef HD_ST
+#undef HD_LG
+#undef HD_STA
+#undef HD_STG
     float* out = partial + ((size_t)(split * 3 + dyi) * M) * N;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
+        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * BM + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int n = nt * BM + wn * 64 + tn * 32 + l31;
-                out[(size_t)m * N + n] = acc[tm][tn][r];
+                const int n = dx * F + nt * BN + wn * 32 + l31;
+                out[(size_t)m * N + n] = acc[tm][dx][r];
             }
     }
 }
@@ -255,10 +291,13 @@ __device__ __forceinline__ float dact_f(float x, int act) {
 }
 
 // Y[b][n] = bias[n] + sum_k act(X[b][k]) * W[n][k]; one wave per output column n, lanes over k
+// grid.y = layer index (the per-block FiLM projections run as one launch): W, bias, Y advance by wstride, bstride, ystride floats
 __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ W, const float* __restrict__ bias,
-                                                      int Bn, int K, int N, int act, float* __restrict__ Y, int ldy) {
+                                                      int Bn, int K, int N, int act, float* __restrict__ Y, int ldy, size_t wstride, size_t bstride,
+                                                      size_t ystride) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
+    W += blockIdx.y * wstride; bias += blockIdx.y * bstride; Y += blockIdx.y * ystride;
     for (int b = 0; b < Bn; ++b) {
         float s = 0.f;
         for (int k = lane; k < K; k += 64) s += act_f(X[(size_t)b * ldx + k], act) * W[(size_t)n * K + k];
@@ -270,8 +309,9 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ 
 
 // dW[n][k] = sum_b dY[b][n] * act(X[b][k]);  db[n] = sum_b dY[b][n]
 __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int Bn, int K, int N,
-                                                        int act, float* __restrict__ dW, float* __restrict__ db) {
+                                                        int act, float* __restrict__ dW, float* __restrict__ db, size_t dystride, size_t wstride, size_t bstride) {
     const int n = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    dY += blockIdx.z * dystride; dW += blockIdx.z * wstride; db += blockIdx.z * bstride;      // grid.z = layer index
     if (k < K) {
         float s = 0.f;
         for (int b = 0; b < Bn; ++b) s += dY[(size_t)b * ldy + n] * act_f(X[(size_t)b * ldx + k], act);
@@ -286,9 +326,11 @@ __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict_
 
 // dX[b][k] (+)= (sum_n dY[b][n] * W[n][k]) * act'(Xpre[b][k])   (act' only when Xpre is given)
 __global__ __launch_bounds__(256) void lin_bwd_x_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ W, int Bn, int K, int N,
-                                                        const float* __restrict__ Xpre, int ldx, int act, int accumulate, float* __restrict__ dX, int lddx) {
+                                                        const float* __restrict__ Xpre, int ldx, int act, int accumulate, float* __restrict__ dX, int lddx,
+                                                        size_t dystride, size_t wstride, size_t xstride) {
     const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
+    dY += blockIdx.z * dystride; W += blockIdx.z * wstride; dX += blockIdx.z * xstride;       // grid.z = layer index (per-layer partials)
     float s = 0.f;
     for (int n = 0; n < N; ++n) s += dY[(size_t)b * ldy + n] * W[(size_t)n * K + k];
     if (Xpre) s *= dact_f(Xpre[(size_t)b * ldx + k], act);
@@ -425,7 +467,7 @@ struct hd_trainer {
     std::vector<float*> X, U;             // X[0..nres], U[0..nres-1]
     float *Y = nullptr, *out = nullptr, *xt = nullptr, *dout = nullptr, *g0 = nullptr, *g1 = nullptr, *g2 = nullptr, *per = nullptr;
     float *emb = nullptr, *h1pre = nullptr, *temb = nullptr, *film = nullptr, *dfilm = nullptr, *dst = nullptr, *dh1 = nullptr, *fpart = nullptr,
-          *spart = nullptr;
+          *spart = nullptr, *mpart = nullptr;
 };
 
 static thread_local std::string t_err;
@@ -515,9 +557,9 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     // weight-gradient operand geometry
     t->P = S + 8;
     const size_t K = ((size_t)B * (S + 1) + 1) * t->P;
-    // 12 tiles per split, each workgroup doing the three row shifts in turn: 40 splits = 480 workgroups = one round of the 512
-    // slots (2 per CU), 5 splits per XCD
-    t->splitK = (int)std::max<size_t>(1, std::min<size_t>(40, K / 2048));
+    // 8 tiles of 128 x 64 (x 3 taps) per split; 64 splits = 512 workgroups = one round at two per CU, 8 splits per XCD
+    const size_t max_split = getenv("HICDIFF_WG_SPLITK") ? (size_t)atoi(getenv("HICDIFF_WG_SPLITK")) : 64;
+    t->splitK = (int)std::max<size_t>(1, std::min<size_t>(max_split, K / 2048));
     if (t->splitK >= 8) t->splitK &= ~7;
     t->Kpad = (K + (size_t)64 * t->splitK - 1) / ((size_t)64 * t->splitK) * ((size_t)64 * t->splitK);
     t->kchunk = t->Kpad / t->splitK;
@@ -525,8 +567,8 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->ld = t->guard + t->Kpad + t->guard;
     t->a_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
     t->a_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
-    t->b_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)3 * F * t->ld, true));
-    t->b_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)3 * F * t->ld, true));
+    t->b_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
+    t->b_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
     t->partial = (float*)need(dev_alloc<float>(t, (size_t)t->splitK * 3 * F * 3 * F));
     t->colpart = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
     t->ctmp = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
@@ -545,6 +587,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     const int nchunk = (S * S + 63) / 64;
     t->fpart = (float*)need(dev_alloc<float>(t, (size_t)B * nchunk * 2 * F));
     t->spart = (float*)need(dev_alloc<float>(t, (size_t)B * ((S + 7) / 8) * F * 18));
+    t->mpart = (float*)need(dev_alloc<float>(t, (size_t)n * B * t->tdim));
     if (!ok) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 2 per block)"); }
     *out = t;
     return HD_OK;
@@ -578,21 +621,18 @@ static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, in
 
 static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
     const int F = tr->F, S = tr->S;
-    if (gside)
-        hipLaunchKernelGGL(wg_prep_kernel<3>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, tr->b_hi, tr->b_lo, mode, film,
-                           2 * F, colpart);
-    else
-        hipLaunchKernelGGL(wg_prep_kernel<1>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, tr->a_hi, tr->a_lo, mode, film,
-                           2 * F, colpart);
+    hipLaunchKernelGGL(wg_prep_kernel, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
+                       gside ? tr->b_lo : tr->a_lo, mode, film, 2 * F, colpart);
     return check_launch("wg_prep");
 }
 
 // dW (+)= scale * wgrad(activation side already in a_*, gradient side already in b_*)
 static int wgrad(hd_trainer* tr, float scale, bool accumulate, float* dW, hipStream_t st) {
-    const int F = tr->F, Mt = F / 128, Nt = 3 * F / 128;
-    hipLaunchKernelGGL(nt_gemm_bf16x3_kernel, dim3(Mt * Nt * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
-                       tr->P, tr->kchunk, tr->splitK, Mt, Nt, F, 3 * F, tr->partial);
-    if (check_launch("nt_gemm")) return -3;
+    const int F = tr->F, Mt = F / 128;
+    static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
+    hipLaunchKernelGGL(wgrad_gemm_kernel, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
+                       tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
+    if (check_launch("wgrad gemm")) return -3;
     const size_t per = (size_t)3 * F * 3 * F;
     hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tr->partial, tr->splitK, F, scale, accumulate ? 1 : 0, dW);
     return check_launch("wg_reduce");
@@ -635,11 +675,11 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     TR_TRY(launch_q_sample(x_start, noise, a_t, s_t, tr->xt, B, S, st));
     hipLaunchKernelGGL(sin_emb_kernel, dim3(B), dim3(256), 0, st, t, F, tr->emb);
     TR_TRY(check_launch("sin_emb"));
-    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->emb, F, params + tr->o_t1w, params + tr->o_t1b, B, F, TD, 0, tr->h1pre, TD);
-    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->h1pre, TD, params + tr->o_t3w, params + tr->o_t3b, B, TD, TD, 2, tr->temb, TD);
-    for (int i = 0; i < n; ++i)
-        hipLaunchKernelGGL(lin_fwd_kernel, dim3((2 * F + 3) / 4), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[i], params + tr->o_mlp_b[i], B, TD, 2 * F, 1,
-                           tr->film + (size_t)i * B * 2 * F, 2 * F);
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->emb, F, params + tr->o_t1w, params + tr->o_t1b, B, F, TD, 0, tr->h1pre, TD, (size_t)0, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->h1pre, TD, params + tr->o_t3w, params + tr->o_t3b, B, TD, TD, 2, tr->temb, TD, (size_t)0, (size_t)0, (size_t)0);
+    const size_t lstride = n > 1 ? tr->o_mlp_w[1] - tr->o_mlp_w[0] : 0;        // every block's slots have the same sizes: a constant stride
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((2 * F + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, 2 * F, 1,
+                       tr->film, 2 * F, lstride, lstride, (size_t)B * 2 * F);
     TR_TRY(check_launch("time/film forward"));
     TR_TRY(launch_conv_small_cin(tr->xt, cond, params + tr->o_head_w, params + tr->o_head_b, tr->X[0], B, S, 3, tr->cin0, F, st));
     const size_t n4 = act / 4;
@@ -711,17 +751,18 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     TR_TRY(check_launch("head wgrad"));
     TR_TRY(colsum(tr, 1.f, false, grads + tr->o_head_b, st));
     // FiLM projections (Linear(SiLU(temb)) per block) and the time MLP
-    for (int i = 0; i < n; ++i) {
-        const float* df = tr->dfilm + (size_t)i * B * 2 * F;
-        hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, 2 * F), dim3(256), 0, st, df, 2 * F, tr->temb, TD, B, TD, 2 * F, 1, grads + tr->o_mlp_w[i],
-                           grads + tr->o_mlp_b[i]);
-        hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B), dim3(256), 0, st, df, 2 * F, params + tr->o_mlp_w[i], B, TD, 2 * F, (const float*)nullptr, 0, 0,
-                           i > 0 ? 1 : 0, tr->dst, TD);
-    }
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, 2 * F, n), dim3(256), 0, st, tr->dfilm, 2 * F, tr->temb, TD, B, TD, 2 * F, 1, grads + tr->o_mlp_w[0],
+                       grads + tr->o_mlp_b[0], (size_t)B * 2 * F, lstride, lstride);
+    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, n), dim3(256), 0, st, tr->dfilm, 2 * F, params + tr->o_mlp_w[0], B, TD, 2 * F, (const float*)nullptr, 0,
+                       0, 0, tr->mpart, TD, (size_t)B * 2 * F, lstride, (size_t)B * TD);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256), 1), dim3(256), 0, st, tr->mpart, n, B * TD, 1.f, 0, tr->dst);
     hipLaunchKernelGGL(dact_mul_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256)), dim3(256), 0, st, tr->dst, tr->temb, (size_t)B * TD, 1);   // d temb
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, TD), dim3(256), 0, st, tr->dst, TD, tr->h1pre, TD, B, TD, TD, 2, grads + tr->o_t3w, grads + tr->o_t3b);
-    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B), dim3(256), 0, st, tr->dst, TD, params + tr->o_t3w, B, TD, TD, tr->h1pre, TD, 2, 0, tr->dh1, TD);
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((F + 255) / 256, TD), dim3(256), 0, st, tr->dh1, TD, tr->emb, F, B, F, TD, 0, grads + tr->o_t1w, grads + tr->o_t1b);
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, TD, 1), dim3(256), 0, st, tr->dst, TD, tr->h1pre, TD, B, TD, TD, 2, grads + tr->o_t3w, grads + tr->o_t3b,
+                       (size_t)0, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, 1), dim3(256), 0, st, tr->dst, TD, params + tr->o_t3w, B, TD, TD, tr->h1pre, TD, 2, 0, tr->dh1, TD,
+                       (size_t)0, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((F + 255) / 256, TD, 1), dim3(256), 0, st, tr->dh1, TD, tr->emb, F, B, F, TD, 0, grads + tr->o_t1w, grads + tr->o_t1b,
+                       (size_t)0, (size_t)0, (size_t)0);
     TR_TRY(check_launch("time mlp backward"));
     return HD_OK;
 }

@@ -55,14 +55,17 @@ def test_conv_kernels_have_no_scratch_and_no_odd_register_broadcast(src):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
     """train.hip: with the prefetch registers in an indexed array hipcc parked them in scratch and waited after every load
-    (8.4 ms per GEMM instead of 1.8).  The GEMM must have no scratch and must issue its 16 loads of a slice back to back."""
+    (4.6x slower).  The GEMM's slice loop must have no scratch traffic and must issue its 13 loads of a slice back to back."""
     text = _asm("train.hip")
     kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S))
-    name = next(k for k in kernels if "nt_gemm_bf16x3_kernel" in k)
-    assert int(re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", kernels[name]).group(1)) == 0
+    name = next(k for k in kernels if "wgrad_gemm_kernel" in k)
     body = text[text.index(name + ":"):]
     body = body[:body.index("s_endpgm")]
-    assert "scratch_" not in body
+    # the slice loop is the innermost loop: no scratch traffic inside it (a few address registers may spill around the outer
+    # row-shift loop, which runs three times)
+    inner = body[body.rindex("Depth=2"):]
+    inner = inner[:inner.index("s_cbranch")]
+    assert "scratch_" not in inner and inner.count("v_mfma") == 72
     ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
     runs, cur = [], 0
     for op in ops:
@@ -72,4 +75,4 @@ def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
             runs.append(cur)
             cur = 0
     runs.append(cur)
-    assert max(runs) >= 16, f"longest run of global loads without a wait: {max(runs)}"
+    assert max(runs) >= 13, f"longest run of global loads without a wait: {max(runs)}"
