@@ -343,13 +343,17 @@ class DiffusionCore(nn.Module):
         """Train mode under autograd -> the native training step (hicdiff_amd/_training.py); eval / no_grad -> loss value only."""
         return self.training and torch.is_grad_enabled() and bool(getattr(self.model, "_native_train", False))
 
-    def _native_loss(self, x_start, cond, t, noise):
+    def _native_loss(self, x_start, cond, t, noise, level=None):
         """loss tensor with `.backward()` (train.py:131-132): forward, loss and every gradient in one engine call."""
         from ._training import trainer_for
         if self.objective != "pred_noise":
             raise NotImplementedError("the reference trains with objective='pred_noise' only")
         if self.loss_type not in ("l1", "l2"):
             raise ValueError(f"invalid loss type {self.loss_type}")
+        if level is not None:                                            # SR3: x_t = level x0 + sqrt(1 - level^2) eps, plain mean
+            tr = trainer_for(self.model, x_start.shape[0], x_start.shape[-1])
+            level = level.reshape(-1).to(x_start.device, torch.float32)
+            return tr.loss_backward(x_start, cond, level, noise, level, (1 - level ** 2).sqrt(), self.loss_type == "l2")
         if self.__dict__.get("_p2_is_one") is None:                      # checked once: it costs a device -> host read
             self.__dict__["_p2_is_one"] = float(self.p2_loss_weight.min()) == 1.0 and float(self.p2_loss_weight.max()) == 1.0
         if not self.__dict__["_p2_is_one"]:

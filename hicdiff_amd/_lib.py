@@ -77,7 +77,7 @@ SYMBOLS = {
     "hd_train_last_error": (C.c_char_p, [_P]),
     "hd_train_param_count": (C.c_int, [_P, _P]),
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
-    "hd_train_loss_backward": (C.c_int, [_P] * 9 + [C.c_int, _P, _P]),
+    "hd_train_loss_backward": (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 3 + [C.c_int, _P, _P]),
     "hd_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
     "hd_split_pieces": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "hd_stitch_pieces": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),

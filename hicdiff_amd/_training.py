@@ -87,10 +87,13 @@ class NativeTrainer:
             raise ValueError(f"trainer sized for batches of {self.B} tiles of {self.S}x{self.S}, got {B} of {S}x{S}")
         f = lambda v: None if v is None else v.detach().to(torch.float32).contiguous()
         x_start, cond, noise, a_t, s_t = f(x_start), f(cond), f(noise), f(a_t), f(s_t)
-        t = t.to(torch.int64).contiguous()
+        if t.dtype.is_floating_point:                       # SR3: the continuous noise level
+            t, kind = t.detach().to(torch.float32).reshape(-1).contiguous(), L.HD_T_FLOAT32
+        else:
+            t, kind = t.to(torch.int64).contiguous(), L.HD_T_INT64
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            rc = self.lib.hd_train_loss_backward(self.h, _ptr(self.flat), _ptr(self.grads), _ptr(x_start), _ptr(cond), _ptr(t), _ptr(noise),
+            rc = self.lib.hd_train_loss_backward(self.h, _ptr(self.flat), _ptr(self.grads), _ptr(x_start), _ptr(cond), _ptr(t), kind, _ptr(noise),
                                                  _ptr(a_t), _ptr(s_t), 1 if l2 else 0, _ptr(self.loss), st)
         if rc != 0:
             raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())

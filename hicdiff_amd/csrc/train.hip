@@ -49,10 +49,12 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
     const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4;
     if (c0 < C) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (mode == 1) {
-            sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c0);
-            sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
-            shf = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + C + c0);
+        if (mode == 1) {                                       // film row: [scale | shift] (film_bs == 2C) or [shift] alone (SR3, film_bs == C)
+            if (film_bs == 2 * C) {
+                sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c0);
+                sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
+            }
+            shf = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + (film_bs - C) + c0);
         }
         const float* src = in + ((size_t)(b * H + y) * W) * C + c0;
         for (int x = pgp; x < W; x += 4) {
@@ -236,8 +238,9 @@ __global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* __restr
     const size_t e = i * 4;
     const int c = (int)(e % C), b = (int)(e / ((size_t)HW * C));
     const float4 v = *reinterpret_cast<const float4*>(u + e);
-    const float4 sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c);
-    const float4 sh = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + C + c);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f);            // SR3 (film_bs == C): additive only, src/model/hicedrn_sr3_Diff.py:254-265
+    if (film_bs == 2 * C) sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c);
+    const float4 sh = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + (film_bs - C) + c);
     float4 o;
     o.x = silu_f(v.x * (sc.x + 1.f) + sh.x); o.y = silu_f(v.y * (sc.y + 1.f) + sh.y);
     o.z = silu_f(v.z * (sc.z + 1.f) + sh.z); o.w = silu_f(v.w * (sc.w + 1.f) + sh.w);
@@ -251,7 +254,8 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ 
     const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x;
     const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
     for (int c = threadIdx.x; c < C; c += 256) {
-        const float sc = film[(size_t)b * film_bs + c] + 1.f, sh = film[(size_t)b * film_bs + C + c];
+        const bool two = film_bs == 2 * C;
+        const float sc = two ? film[(size_t)b * film_bs + c] + 1.f : 1.f, sh = film[(size_t)b * film_bs + (film_bs - C) + c];
         float s_scale = 0.f, s_shift = 0.f;
         for (int p = p0; p < p1; ++p) {
             const size_t e = ((size_t)b * HW + p) * C + c;
@@ -262,8 +266,9 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ 
             s_scale += dv * uu; s_shift += dv;
             g[e] = dv * sc;
         }
-        float* d = part + ((size_t)(b * nchunk + ck) * 2) * C;
-        d[c] = s_scale; d[C + c] = s_shift;
+        float* d = part + (size_t)(b * nchunk + ck) * film_bs;      // [d scale | d shift], or [d shift] alone
+        if (two) d[c] = s_scale;
+        d[(film_bs - C) + c] = s_shift;
     }
 }
 
@@ -345,12 +350,13 @@ __global__ __launch_bounds__(256) void dact_mul_kernel(float* __restrict__ x, co
 }
 
 // SinusoidalPosEmb (src/model/hicedrn_Diff.py:122-134): emb[b] = [sin(t f_k), cos(t f_k)], f_k = exp(-k ln(1e4)/(half-1))
-__global__ __launch_bounds__(256) void sin_emb_kernel(const long long* __restrict__ t, int dim, float* __restrict__ emb) {
+// SR3 PositionalEncoding of the continuous noise level (src/hicdiff_sr3.py:155-165): f_k = exp(-ln(1e4) k / half)
+__global__ __launch_bounds__(256) void sin_emb_kernel(const void* __restrict__ t, int t_float, int sr3, int dim, float* __restrict__ emb) {
     const int b = blockIdx.x, half = dim / 2;
-    const float tv = (float)t[b];
+    const float tv = t_float ? reinterpret_cast<const float*>(t)[b] : (float)reinterpret_cast<const long long*>(t)[b];
     for (int i = threadIdx.x; i < dim; i += 256) {
         const int k = i < half ? i : i - half;
-        const float a = tv * expf((float)k * -(9.210340371976184f / (float)(half - 1)));
+        const float a = tv * (sr3 ? expf(-9.210340371976184f * ((float)k / (float)half)) : expf((float)k * -(9.210340371976184f / (float)(half - 1))));
         emb[(size_t)b * dim + i] = i < half ? sinf(a) : cosf(a);
     }
 }
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // =====================================================================================================================
 struct hd_trainer {
     hd_arch_desc arch{};
-    int device = 0, B = 0, S = 0, F = 256, nres = 0, cin0 = 1, tdim = 1024;
+    int device = 0, B = 0, S = 0, F = 256, nres = 0, cin0 = 1, tdim = 1024, FW = 512;   // FW: FiLM row width (2F; F for SR3's additive form)
     std::string err;
     struct Slot { std::string name; size_t off, n; int ndim; long long shape[4]; };
     std::vector<Slot> slots;
@@ -509,13 +515,14 @@ void hd_train_destroy(hd_trainer* t) {
 int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, int S) {
     if (!out || !a) return HD_EINVAL;
     *out = nullptr;
-    if (a->kind != HD_ARCH_HICEDRN || a->sr3) return tfail(nullptr, HD_EINVAL, "native training covers hicedrn_Diff (unconditional / self_condition); UNet and SR3 are not built yet");
+    if (a->kind != HD_ARCH_HICEDRN) return tfail(nullptr, HD_EINVAL, "native training covers the hicedrn networks (unconditional / self_condition / SR3); the UNet is not built yet");
     if (a->dim != 256 || a->number_resnet < 1) return tfail(nullptr, HD_EINVAL, "hicedrn: n_feat must be 256");
     if (B < 1 || S < 8 || S > 64 || S % 8) return tfail(nullptr, HD_EINVAL, "training tiles: 8 <= S <= 64, S a multiple of 8");
     if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, HD_EHIP, "hipSetDevice failed");
     hd_trainer* t = new hd_trainer();
     t->arch = *a; t->device = device; t->B = B; t->S = S; t->F = a->dim; t->nres = a->number_resnet; t->cin0 = a->self_condition ? 2 : 1;
     t->tdim = 4 * t->F;
+    t->FW = a->sr3 ? t->F : 2 * t->F;
     const int F = t->F, n = t->nres;
     // flat parameter layout = the reference's state_dict order (tests/golden/param_inventory.json)
     add_slot(t, "head.weight", {F, t->cin0, 3, 3}, &t->o_head_w);
@@ -527,8 +534,9 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->o_mlp_w.resize(n); t->o_mlp_b.resize(n); t->o_conv_w.resize(n + 1); t->o_conv_b.resize(n + 1);
     for (int i = 0; i < n; ++i) {
         const std::string p = "body." + std::to_string(i);
-        add_slot(t, p + ".mlp.1.weight", {2 * F, t->tdim}, &t->o_mlp_w[i]);
-        add_slot(t, p + ".mlp.1.bias", {2 * F}, &t->o_mlp_b[i]);
+        const std::string film = a->sr3 ? ".noise_func.noise_func.0" : ".mlp.1";          // src/model/hicedrn_sr3_Diff.py FeatureWiseAffine
+        add_slot(t, p + film + ".weight", {t->FW, t->tdim}, &t->o_mlp_w[i]);
+        add_slot(t, p + film + ".bias", {t->FW}, &t->o_mlp_b[i]);
         add_slot(t, p + ".conv.proj.weight", {F, F, 3, 3}, &t->o_conv_w[i]);
         add_slot(t, p + ".conv.proj.bias", {F}, &t->o_conv_b[i]);
     }
@@ -582,7 +590,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->per = (float*)need(dev_alloc<float>(t, 2 * B));
     t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
-    t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));
+    t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));   // sized for the wider form
     t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     const int nchunk = (S * S + 63) / 64;
     t->fpart = (float*)need(dev_alloc<float>(t, (size_t)B * nchunk * 2 * F));
@@ -622,7 +630,7 @@ static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, in
 static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
     const int F = tr->F, S = tr->S;
     hipLaunchKernelGGL(wg_prep_kernel, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
-                       gside ? tr->b_lo : tr->a_lo, mode, film, 2 * F, colpart);
+                       gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
     return check_launch("wg_prep");
 }
 
@@ -645,12 +653,16 @@ static int colsum(hd_trainer* tr, float scale, bool accumulate, float* db, hipSt
     return check_launch("colsum");
 }
 
-extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float* grads, const float* x_start, const float* cond, const long long* t,
+extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float* grads, const float* x_start, const float* cond, const void* t, int t_kind,
                                       const float* noise, const float* a_t, const float* s_t, int l2, float* loss, void* stream) {
     if (!tr || !params || !grads || !x_start || !t || !noise || !a_t || !s_t || !loss) return HD_EINVAL;
     if ((tr->cin0 == 2) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
     hipStream_t st = (hipStream_t)stream;
-    const int F = tr->F, S = tr->S, B = tr->B, n = tr->nres, TD = tr->tdim, HW = S * S;
+    const int F = tr->F, S = tr->S, B = tr->B, n = tr->nres, TD = tr->tdim, HW = S * S, FW = tr->FW;
+    const bool sr3 = tr->arch.sr3 != 0;
+    const int t_float = t_kind == HD_T_FLOAT32 ? 1 : 0;
+    if (t_kind != HD_T_INT64 && t_kind != HD_T_FLOAT32) return tfail(tr, HD_EINVAL, "t_kind must be HD_T_INT64 or HD_T_FLOAT32");
+    if (sr3 != (t_float != 0)) return tfail(tr, HD_EINVAL, "SR3 nets take the continuous noise level (float32); the others integer timesteps");
     const size_t act = (size_t)B * HW * F;
     tr->err.clear();
     // ---- weights: forward image, flipped-transposed image for the data gradient
@@ -673,20 +685,21 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
 
     // ---- forward (src/hicdiff.py:694-700,711-747; src/model/hicedrn_Diff.py:267-289)
     TR_TRY(launch_q_sample(x_start, noise, a_t, s_t, tr->xt, B, S, st));
-    hipLaunchKernelGGL(sin_emb_kernel, dim3(B), dim3(256), 0, st, t, F, tr->emb);
+    hipLaunchKernelGGL(sin_emb_kernel, dim3(B), dim3(256), 0, st, t, t_float, sr3 ? 1 : 0, F, tr->emb);
     TR_TRY(check_launch("sin_emb"));
     hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->emb, F, params + tr->o_t1w, params + tr->o_t1b, B, F, TD, 0, tr->h1pre, TD, (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->h1pre, TD, params + tr->o_t3w, params + tr->o_t3b, B, TD, TD, 2, tr->temb, TD, (size_t)0, (size_t)0, (size_t)0);
     const size_t lstride = n > 1 ? tr->o_mlp_w[1] - tr->o_mlp_w[0] : 0;        // every block's slots have the same sizes: a constant stride
-    hipLaunchKernelGGL(lin_fwd_kernel, dim3((2 * F + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, 2 * F, 1,
-                       tr->film, 2 * F, lstride, lstride, (size_t)B * 2 * F);
+    // non-SR3: Linear(SiLU(temb)) -> (scale, shift) (src/model/hicedrn_Diff.py:185-199); SR3: Linear(temb) -> shift (hicedrn_sr3_Diff.py:167-183)
+    hipLaunchKernelGGL(lin_fwd_kernel, dim3((FW + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, FW, sr3 ? 0 : 1,
+                       tr->film, FW, lstride, lstride, (size_t)B * FW);
     TR_TRY(check_launch("time/film forward"));
     TR_TRY(launch_conv_small_cin(tr->xt, cond, params + tr->o_head_w, params + tr->o_head_b, tr->X[0], B, S, 3, tr->cin0, F, st));
     const size_t n4 = act / 4;
     for (int i = 0; i < n; ++i) {
-        const float* film = tr->film + (size_t)i * B * 2 * F;
+        const float* film = tr->film + (size_t)i * B * FW;
         TR_TRY(conv3(tr, tr->fwd[i], tr->X[i], tr->U[i], 0, 1.f, nullptr, st));
-        hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, 2 * F, HW, F, n4, tr->g0);
+        hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, FW, HW, F, n4, tr->g0);
         TR_TRY(check_launch("film_silu_fwd"));
         TR_TRY(conv3(tr, tr->fwd[i], tr->g0, tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
     }
@@ -720,7 +733,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     TR_TRY(conv3(tr, tr->bwd[n], dY, dx, 0, 1.f, nullptr, st));
     const int nchunk = (HW + 63) / 64;
     for (int i = n - 1; i >= 0; --i) {
-        const float* film = tr->film + (size_t)i * B * 2 * F;
+        const float* film = tr->film + (size_t)i * B * FW;
         float* dW = grads + tr->o_conv_w[i];
         float* db = grads + tr->o_conv_b[i];
         // second use of the conv: y = 0.1 conv(a) + x
@@ -729,8 +742,8 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         TR_TRY(wgrad(tr, 0.1f, false, dW, st));
         TR_TRY(colsum(tr, 0.1f, false, db, st));
         TR_TRY(conv3(tr, tr->bwd[i], dx, da, 0, 1.f, nullptr, st));              // dL/da / 0.1
-        hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, 2 * F, HW, F, 64, 0.1f, tr->fpart);
-        hipLaunchKernelGGL(sum_rows_kernel, dim3((2 * F + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, 2 * F, 1.f, 0, tr->dfilm + (size_t)i * B * 2 * F);
+        hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, FW, HW, F, 64, 0.1f, tr->fpart);
+        hipLaunchKernelGGL(sum_rows_kernel, dim3((FW + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, FW, 1.f, 0, tr->dfilm + (size_t)i * B * FW);
         TR_TRY(check_launch("film_silu_bwd"));
         // first use: u = conv(x)
         TR_TRY(prep(tr, tr->X[i], false, 0, nullptr, nullptr, st));
@@ -751,12 +764,12 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     TR_TRY(check_launch("head wgrad"));
     TR_TRY(colsum(tr, 1.f, false, grads + tr->o_head_b, st));
     // FiLM projections (Linear(SiLU(temb)) per block) and the time MLP
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, 2 * F, n), dim3(256), 0, st, tr->dfilm, 2 * F, tr->temb, TD, B, TD, 2 * F, 1, grads + tr->o_mlp_w[0],
-                       grads + tr->o_mlp_b[0], (size_t)B * 2 * F, lstride, lstride);
-    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, n), dim3(256), 0, st, tr->dfilm, 2 * F, params + tr->o_mlp_w[0], B, TD, 2 * F, (const float*)nullptr, 0,
-                       0, 0, tr->mpart, TD, (size_t)B * 2 * F, lstride, (size_t)B * TD);
+    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, FW, n), dim3(256), 0, st, tr->dfilm, FW, tr->temb, TD, B, TD, FW, sr3 ? 0 : 1, grads + tr->o_mlp_w[0],
+                       grads + tr->o_mlp_b[0], (size_t)B * FW, lstride, lstride);
+    hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, n), dim3(256), 0, st, tr->dfilm, FW, params + tr->o_mlp_w[0], B, TD, FW, (const float*)nullptr, 0,
+                       0, 0, tr->mpart, TD, (size_t)B * FW, lstride, (size_t)B * TD);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256), 1), dim3(256), 0, st, tr->mpart, n, B * TD, 1.f, 0, tr->dst);
-    hipLaunchKernelGGL(dact_mul_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256)), dim3(256), 0, st, tr->dst, tr->temb, (size_t)B * TD, 1);   // d temb
+    if (!sr3) hipLaunchKernelGGL(dact_mul_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256)), dim3(256), 0, st, tr->dst, tr->temb, (size_t)B * TD, 1);   // d silu(temb) -> d temb
     hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, TD, 1), dim3(256), 0, st, tr->dst, TD, tr->h1pre, TD, B, TD, TD, 2, grads + tr->o_t3w, grads + tr->o_t3b,
                        (size_t)0, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, 1), dim3(256), 0, st, tr->dst, TD, params + tr->o_t3w, B, TD, TD, tr->h1pre, TD, 2, 0, tr->dh1, TD,

@@ -52,6 +52,8 @@ class GaussianDiffusion(_CondDiffusion):
         level = level.to(x_end.device).view(b, -1)
         if noise is None:
             noise = self.noise_source.randn(x_end.shape) if self.noise_source is not None else torch.randn_like(x_end)
+        if self._native_training():
+            return self._native_loss(x_end, x_start if self.self_condition else None, None, noise, level=level)
         x = self.q_sample(x_start=x_end, continuous_sqrt_alpha_cumprod=level.view(-1, 1, 1, 1), noise=noise)
         out = self.model(x, level, x_start if self.self_condition else None)
         return self._loss_value(out, self._target(x_end, None, noise), None)   # plain mean, no p2 weight (:786-791)

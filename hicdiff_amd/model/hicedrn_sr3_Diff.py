@@ -6,7 +6,7 @@ from .hicedrn_Diff import hicedrn_Diff as _Base, n_feat, kernel_size  # noqa: F4
 
 class hicedrn_Diff(_Base):
     _SR3 = True
-    _native_train = False      # the SR3 flavour is not covered by the native training step yet
+    _native_train = True       # hd_train_* covers the SR3 flavour too (additive FiLM, continuous noise level)
 
     def __init__(self, channels=1, out_dim=None, number_resnet=32, self_condition=False,
                  learned_sinusoidal_cond=False, noise_level_emb=True, learned_sinusoidal_dim=16):

@@ -210,7 +210,8 @@ int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, 
  * train.py:109-134 with torch autograd (p_losses src/hicdiff.py:711-747, src/hicdiff_condition.py:715-746; net
  * src/model/hicedrn_Diff.py:169-289; optim.Adam(lr=2e-5) train.py:111).  The caller owns four flat fp32 device arrays
  * (params, grads, and Adam's m, v) laid out as hd_train_param_slot describes: the reference's state_dict order, every tensor
- * in torch layout at a 16-byte aligned offset.  UNet and SR3 nets are not covered yet (hd_train_create returns HD_EINVAL). */
+ * in torch layout at a 16-byte aligned offset.  Covers hicedrn_Diff (unconditional, self_condition) and its SR3 flavour
+ * (src/model/hicedrn_sr3_Diff.py:245-352); the UNet is not covered yet (hd_train_create returns HD_EINVAL). */
 typedef struct hd_trainer hd_trainer;
 
 /* Sizes the saved activations for batches of exactly B tiles of 1xSxS (two tensors of B*S*S*256 floats per residual block). */
@@ -224,11 +225,12 @@ int hd_train_param_count(const hd_trainer* t, long long* total_floats);
 int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long* offset, long long* shape4, int* ndim);
 
 /* x_t = a_t[b] x_start + s_t[b] noise; eps_hat = net(x_t, t, cond); loss = mean_b mean_pixels f(eps_hat - noise), f = square
- * (l2 != 0) or abs; grads <- d loss / d params (every slot overwritten).  t: int64[B]; a_t, s_t: float[B] =
- * sqrt_alphas_cumprod[t], sqrt_one_minus_alphas_cumprod[t] (src/hicdiff.py:694-700); cond: the low-coverage tiles iff
- * self_condition; loss: one device float.  Only enqueues on the stream; deterministic (no atomics). */
+ * (l2 != 0) or abs; grads <- d loss / d params (every slot overwritten).  timesteps: int64[B] (t_kind HD_T_INT64) with a_t, s_t:
+ * float[B] = sqrt_alphas_cumprod[t], sqrt_one_minus_alphas_cumprod[t] (src/hicdiff.py:694-700); SR3 nets instead take the
+ * continuous noise level float[B] (t_kind HD_T_FLOAT32) with a_t = level, s_t = sqrt(1 - level^2) (src/hicdiff_sr3.py:735-792).
+ * cond: the low-coverage tiles iff self_condition; loss: one device float.  Only enqueues on the stream; deterministic. */
 int hd_train_loss_backward(hd_trainer* t, const float* params, float* grads, const float* x_start, const float* cond,
-                           const long long* timesteps, const float* noise, const float* a_t, const float* s_t, int l2, float* loss,
+                           const void* timesteps, int t_kind, const float* noise, const float* a_t, const float* s_t, int l2, float* loss,
                            void* stream);
 
 /* torch.optim.Adam without weight decay / amsgrad over one flat array, one launch: g = grads * grad_scale (1/world after a

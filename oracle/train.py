@@ -14,14 +14,20 @@ from . import nets as ON
 
 
 def loss_and_grads(sd, cfg, buf, x0, t, eps, cond=None, loss_type="l2"):
+    """t: int64 timesteps; for SR3 nets (cfg.sr3) the continuous noise level as a float tensor (src/hicdiff_sr3.py:750-792:
+    x_t = level x0 + sqrt(1 - level^2) eps, plain mean reduction)."""
     p = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
-    a = buf["sqrt_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
-    s = buf["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
-    x = a * x0 + s * eps
     fn = ON.unet_eps if isinstance(cfg, ON.UnetCfg) else ON.hicedrn_eps
-    out = fn(p, x, t, cond, cfg)
-    per = (out - eps).abs() if loss_type == "l1" else (out - eps) ** 2
-    loss = (per.reshape(per.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"].gather(-1, t)).mean()
+    if cfg.sr3:
+        lv = t.float().reshape(-1, 1, 1, 1)
+        out = fn(p, lv * x0 + (1 - lv ** 2).sqrt() * eps, t.float().reshape(-1, 1), cond, cfg)
+        loss = ((out - eps).abs() if loss_type == "l1" else (out - eps) ** 2).mean()
+    else:
+        a = buf["sqrt_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
+        s = buf["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
+        out = fn(p, a * x0 + s * eps, t, cond, cfg)
+        per = (out - eps).abs() if loss_type == "l1" else (out - eps) ** 2
+        loss = (per.reshape(per.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"].gather(-1, t)).mean()
     loss.backward()
     return loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}
 

@@ -452,10 +452,12 @@ def case_train():
     out = {}
     B, S, T = 3, 16, 1000
     x0, lq = tiles(21, B, S), tiles(22, B, S)
-    for kind in ("cond", "uncond"):
+    for kind in ("cond", "uncond", "sr3"):
         m, cfg = build_hicedrn(kind, 2)
         m.train()
-        d = (R1 if kind == "cond" else R0).GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        T = 2000 if kind == "sr3" else 1000
+        d = {"cond": R1, "uncond": R0, "sr3": R2}[kind].GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        oref = OD.DiffusionRef(None, image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="sr3") if kind == "sr3" else None
         names = [k for k, _ in m.named_parameters()]
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         buf = OD.diffusion_buffers("linear", T)
@@ -465,13 +467,17 @@ def case_train():
         op = {k: sd[k].clone() for k in names}
         with torch.enable_grad():
             for step in range(1, 4):
+                np.random.seed(70 + step)
                 torch.manual_seed(300 + step)
-                loss = d([lq, x0] if kind == "cond" else x0)
+                loss = d(x0 if kind == "uncond" else [lq, x0])
                 loss.backward()
                 torch.manual_seed(300 + step)
-                t = torch.randint(0, T, (B,)).long()
+                if kind == "sr3":                              # level from numpy's generator, noise from torch's (src/hicdiff_sr3.py:754-763)
+                    t = oref.sr3_draw_level(np.random.RandomState(70 + step), B)
+                else:
+                    t = torch.randint(0, T, (B,)).long()
                 eps = torch.randn_like(x0)
-                ol, og = OTR.loss_and_grads(op, cfg, buf, x0, t, eps, lq if kind == "cond" else None, "l2")
+                ol, og = OTR.loss_and_grads(op, cfg, buf, x0, t, eps, None if kind == "uncond" else lq, "l2")
                 check(f"train {kind} step {step} loss", loss.detach(), ol, tol=1e-6)
                 for k, prm in m.named_parameters():
                     check(f"  grad {k}", prm.grad, og[k], tol=2e-5) if step == 1 else None

@@ -16,18 +16,27 @@ def _diffusion(kind, nres, S, loss="l2", schedule="linear"):
     m = product_hicedrn(kind, nres)
     if kind == "cond":
         from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+    elif kind == "sr3":
+        from hicdiff_amd.hicdiff_sr3 import GaussianDiffusion
     else:
         from hicdiff_amd.hicdiff import GaussianDiffusion
-    return GaussianDiffusion(m, image_size=S, timesteps=1000, loss_type=loss, beta_schedule=schedule).cuda()
+    return GaussianDiffusion(m, image_size=S, timesteps=2000 if kind == "sr3" else 1000, loss_type=loss, beta_schedule=schedule).cuda()
 
 
 def _oracle_sd(kind, nres):
     from oracle import nets as ON, weights as W
-    cfg = ON.HicedrnCfg(number_resnet=nres, self_condition=(kind != "uncond"), sr3=False)
-    return W.fill_state_dict(W.hicedrn_shapes(number_resnet=nres, self_condition=cfg.self_condition, sr3=False)), cfg
+    cfg = ON.HicedrnCfg(number_resnet=nres, self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    return W.fill_state_dict(W.hicedrn_shapes(number_resnet=nres, self_condition=cfg.self_condition, sr3=cfg.sr3)), cfg
 
 
-@pytest.mark.parametrize("kind", ["cond", "uncond"])
+def _loss(d, kind, lq, x0, t, eps):
+    """p_losses with given draws: integer timesteps, or (SR3) the continuous noise level."""
+    if kind == "sr3":
+        return d.p_losses([lq, x0], noise=eps, level=t)
+    return d.p_losses([lq, x0], t, eps) if kind == "cond" else d.p_losses(x0, t, eps)
+
+
+@pytest.mark.parametrize("kind", ["cond", "uncond", "sr3"])
 def test_train_three_steps_golden(kind):
     """loss = diffusion(x); loss.backward(); Adam(lr=2e-5).step() -- three steps on the 2-block hicedrn the reference ran
     (tests/golden/make_golden.py::case_train): losses, a fixed subset + the norm of every gradient, parameters after each step."""
@@ -42,7 +51,7 @@ def test_train_three_steps_golden(kind):
     start = {k: p.detach().clone() for k, p in d.model.named_parameters()}
     for step in (1, 2, 3):
         t, eps = g[f"{kind}_s{step}_t"].cuda(), g[f"{kind}_s{step}_eps"].cuda()
-        loss = d.p_losses([lq, x0], t, eps) if kind == "cond" else d.p_losses(x0, t, eps)
+        loss = _loss(d, kind, lq, x0, t, eps)
         assert loss.requires_grad
         loss.backward()
         assert abs(float(loss.detach()) - float(g[f"{kind}_s{step}_loss"])) <= 1e-4 * float(g[f"{kind}_s{step}_loss"])
@@ -64,7 +73,8 @@ def test_train_three_steps_golden(kind):
     assert list(d.model.state_dict().keys()) == names           # checkpoint keys untouched by the flat re-seating
 
 
-@pytest.mark.parametrize("kind,loss,B,S,nres", [("cond", "l2", 4, 40, 3), ("uncond", "l1", 2, 64, 2), ("cond", "l2", 5, 24, 1)])
+@pytest.mark.parametrize("kind,loss,B,S,nres", [("cond", "l2", 4, 40, 3), ("uncond", "l1", 2, 64, 2), ("cond", "l2", 5, 24, 1), ("sr3", "l2", 3, 40, 2),
+                                                 ("sr3", "l1", 2, 16, 1)])
 def test_train_gradients_vs_autograd_oracle(kind, loss, B, S, nres):
     """Every entry of every gradient against torch autograd over the oracle net (CPU fp32)."""
     from oracle import diffusion as OD, train as OTR
@@ -73,12 +83,12 @@ def test_train_gradients_vs_autograd_oracle(kind, loss, B, S, nres):
     sd, cfg = _oracle_sd(kind, nres)
     x0, lq = tiles(31, B, S), tiles(32, B, S)
     gen = torch.Generator().manual_seed(5)
-    t = torch.randint(0, 1000, (B,), generator=gen)
+    t = torch.rand((B,), generator=gen) * 0.9 + 0.05 if kind == "sr3" else torch.randint(0, 1000, (B,), generator=gen)
     eps = torch.randn(x0.shape, generator=gen)
-    ol, og = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("sigmoid", 1000), x0, t, eps, lq if kind == "cond" else None, loss)
-    val = d.p_losses([lq.cuda(), x0.cuda()], t.cuda(), eps.cuda()) if kind == "cond" else d.p_losses(x0.cuda(), t.cuda(), eps.cuda())
+    ol, og = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("sigmoid", 1000), x0, t, eps, None if kind == "uncond" else lq, loss)
+    val = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
     val.backward()
-    assert abs(float(val) - float(ol)) <= 1e-4 * float(ol)
+    assert abs(float(val.detach()) - float(ol)) <= 1e-4 * float(ol)
     worst = {}
     for k, p in d.model.named_parameters():
         worst[k] = rel_err(og[k], p.grad)
@@ -88,7 +98,7 @@ def test_train_gradients_vs_autograd_oracle(kind, loss, B, S, nres):
     first = {k: p.grad.clone() for k, p in d.model.named_parameters()}
     for p in d.model.parameters():
         p.grad = None
-    val2 = d.p_losses([lq.cuda(), x0.cuda()], t.cuda(), eps.cuda()) if kind == "cond" else d.p_losses(x0.cuda(), t.cuda(), eps.cuda())
+    val2 = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
     val2.backward()
     assert torch.equal(val, val2) and all(torch.equal(first[k], p.grad) for k, p in d.model.named_parameters())
 

@@ -202,20 +202,20 @@ def test_tiles_edge_cases_and_degradation():
     assert np.array_equal(noisy, g["deg_noisy"]) and np.array_equal(sample, g["deg_sample"])
 
 
-@pytest.mark.parametrize("kind", ["cond", "uncond"])
+@pytest.mark.parametrize("kind", ["cond", "uncond", "sr3"])
 def test_train_oracle_reproduces_reference_gradients_and_adam(kind):
     """oracle/train.py (autograd over the oracle net + the Adam restatement) against what the reference's own
     `loss.backward(); torch.optim.Adam.step()` produced for three steps (make_golden.py::case_train)."""
     from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
     g = np.load(os.path.join(GOLDEN, "train.npz"))
-    cfg = ON.HicedrnCfg(number_resnet=2, self_condition=(kind == "cond"), sr3=False)
-    sd = W.fill_state_dict(W.hicedrn_shapes(number_resnet=2, self_condition=cfg.self_condition, sr3=False))
+    cfg = ON.HicedrnCfg(number_resnet=2, self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    sd = W.fill_state_dict(W.hicedrn_shapes(number_resnet=2, self_condition=cfg.self_condition, sr3=cfg.sr3))
     buf = OD.diffusion_buffers("linear", 1000)
     m, v = {k: torch.zeros_like(p) for k, p in sd.items()}, {k: torch.zeros_like(p) for k, p in sd.items()}
     x0, lq = torch.from_numpy(g["x0"]), torch.from_numpy(g["lq"])
     for step in (1, 2, 3):
         t, eps = torch.from_numpy(g[f"{kind}_s{step}_t"]), torch.from_numpy(g[f"{kind}_s{step}_eps"])
-        loss, grads = OTR.loss_and_grads(sd, cfg, buf, x0, t, eps, lq if kind == "cond" else None, "l2")
+        loss, grads = OTR.loss_and_grads(sd, cfg, buf, x0, t, eps, None if kind == "uncond" else lq, "l2")
         assert abs(float(loss) - float(g[f"{kind}_s{step}_loss"])) <= 1e-6 * float(loss)
         for k in sd:
             ref = torch.from_numpy(g[f"{kind}_s{step}_grad_sample/{k}"])
