@@ -69,6 +69,15 @@ void conv_prof_begin(const ConvLaunch& L, const char* name, hipStream_t st) {
     (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
     (void)hipEventRecord(g_cur.e0, st);
 }
+// the same bracket for kernels outside the convolution launcher (training: weight-gradient GEMM, operand rewrite); `name` must be a
+// string literal or otherwise outlive the profile (rows are keyed by pointer)
+void hd_prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
+    if (!g_prof_on) return;
+    g_cur = ProfRec{};
+    g_cur.name = name; g_cur.flops = flops; g_cur.bytes = bytes;
+    (void)hipEventCreate(&g_cur.e0); (void)hipEventCreate(&g_cur.e1);
+    (void)hipEventRecord(g_cur.e0, st);
+}
 void conv_prof_end(hipStream_t st) {
     if (!g_prof_on) return;
     (void)hipEventRecord(g_cur.e1, st);

@@ -81,6 +81,8 @@ void hd_set_error(const std::string& msg);
 
 void hd_prof_enable(bool on);
 bool hd_prof_is_on();
+void hd_prof_begin(const char* name, double flops, double bytes, hipStream_t st);   // + conv_prof_end(st) after the launch
+void conv_prof_end(hipStream_t st);
 int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes, long long* launches, int max_rows);   // returns the row count
 
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------

@@ -629,8 +629,10 @@ static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, in
 
 static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
     const int F = tr->F, S = tr->S;
+    hd_prof_begin("wg_prep_kernel", 0.0, (double)tr->B * S * S * F * (4.0 + 4.0), st);          // fp32 in, bf16 hi + lo out
     hipLaunchKernelGGL(wg_prep_kernel, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
                        gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
+    conv_prof_end(st);
     return check_launch("wg_prep");
 }
 
@@ -638,8 +640,12 @@ static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const flo
 static int wgrad(hd_trainer* tr, float scale, bool accumulate, float* dW, hipStream_t st) {
     const int F = tr->F, Mt = F / 128;
     static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
+    // algorithmic figures: 9 taps x F x F outputs over the B*S*S real pixels (3 MFMA flops per product are the kernel's business);
+    // bytes: both operand images once (hi + lo) + the partials
+    hd_prof_begin("wgrad_gemm_kernel", 2.0 * 9 * F * F * (double)tr->B * tr->S * tr->S, 2.0 * 2 * 2 * F * (double)tr->Kpad + 4.0 * tr->splitK * 9 * F * F, st);
     hipLaunchKernelGGL(wgrad_gemm_kernel, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
                        tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
+    conv_prof_end(st);
     if (check_launch("wgrad gemm")) return -3;
     const size_t per = (size_t)3 * F * 3 * F;
     hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tr->partial, tr->splitK, F, scale, accumulate ? 1 : 0, dW);
