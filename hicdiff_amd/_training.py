@@ -97,7 +97,8 @@ class NativeTrainer:
                                                  _ptr(a_t), _ptr(s_t), 1 if l2 else 0, _ptr(self.loss), st)
         if rc != 0:
             raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
-        return _NativeLoss.apply(self.anchor, self, self.loss.clone())
+        self.serial = getattr(self, "serial", 0) + 1
+        return _NativeLoss.apply(self.anchor, self, self.loss.clone(), self.serial)
 
     def weights_changed(self):
         self.model.__dict__["_hd_weight_epoch"] = self.model.__dict__.get("_hd_weight_epoch", 0) + 1
@@ -107,13 +108,16 @@ class _NativeLoss(torch.autograd.Function):
     """The gradients already exist when the loss is returned; backward() only publishes them as `.grad`."""
 
     @staticmethod
-    def forward(ctx, anchor, trainer, value):
-        ctx.trainer = trainer
+    def forward(ctx, anchor, trainer, value, serial):
+        ctx.trainer, ctx.serial = trainer, serial
         return value
 
     @staticmethod
     def backward(ctx, grad_out):
         tr = ctx.trainer
+        if ctx.serial != tr.serial:
+            raise RuntimeError("this loss is stale: the gradient buffer holds the gradients of a later diffusion(x) call "
+                               "(call loss.backward() before the next forward in train mode)")
         one = bool((grad_out == 1).item())
         if not one:
             tr.grads.mul_(grad_out)
@@ -123,7 +127,7 @@ class _NativeLoss(torch.autograd.Function):
                 p.grad = g                        # a view of the flat gradient buffer: Adam below reads it in place
             elif p.grad.data_ptr() != g.data_ptr():
                 p.grad.add_(g)                    # accumulation over several backward() calls, as autograd would
-        return None, None, None
+        return None, None, None, None
 
 
 def trainer_for(model, B: int, S: int) -> NativeTrainer:

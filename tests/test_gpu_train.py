@@ -104,7 +104,7 @@ def test_train_gradients_vs_autograd_oracle(kind, loss, B, S, nres):
 
 
 def test_train_loop_matches_oracle_loss_curve_and_serves_updated_weights():
-    """Ten steps of the reference loop (forward draws t and noise itself): the loss curve follows the oracle's Adam run on the
+    """Twenty steps of the reference loop (forward draws t and noise itself): the loss curve follows the oracle's Adam run on the
     same draws; afterwards eval-mode sampling uses the UPDATED weights (the inference engine re-packs), and a state_dict round trip
     through a fresh module reproduces eps."""
     from hicdiff_amd.optim import Adam
@@ -118,7 +118,7 @@ def test_train_loop_matches_oracle_loss_curve_and_serves_updated_weights():
     om, ov = {k: torch.zeros_like(v) for k, v in sd.items()}, {k: torch.zeros_like(v) for k, v in sd.items()}
     x0, lq = tiles(41, B, S).cuda(), tiles(42, B, S).cuda()
     before = d.model(x0, torch.full((B,), 10, device="cuda"), lq).clone()
-    for step in range(1, 11):
+    for step in range(1, 21):
         torch.manual_seed(500 + step)
         loss = d([lq, x0])
         loss.backward()
@@ -153,6 +153,11 @@ def test_train_errors():
         Adam([torch.nn.Parameter(torch.zeros(1))], lr=1e-3, weight_decay=0.1)
     d = _diffusion("uncond", 1, 16)
     d.train()
+    first = d(tiles(1, 2, 16).cuda())
+    second = d(tiles(2, 2, 16).cuda())
+    with pytest.raises(RuntimeError):
+        first.backward()                                  # its gradients were overwritten by the second forward
+    second.backward()
     with pytest.raises(AssertionError):
         d(tiles(1, 2, 24).cuda())                         # wrong tile size: the reference's assert
 
