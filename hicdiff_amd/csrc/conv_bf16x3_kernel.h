@@ -129,6 +129,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
 
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
+    // split-K (3x3 only): grid.y picks a run of K slices; this workgroup writes its raw sums to its own slab of the workspace
+    int cb = 0;
+    if constexpr (NTAPS == 9) {
+        if (p.ksplit > 1) { cb = blockIdx.y * p.kchunks; p.out += (size_t)blockIdx.y * p.split_stride; }
+    }
     if (p.stagger) {
         const int mode = p.stagger >> 16, n = p.stagger & 0xffff, b = blockIdx.x;
         const bool hit = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : (b >> 3) & 1);
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
     float4 pr0 = make_float4(0.f, 0.f, 0.f, 0.f), pr1 = pr0, pr2 = pr0;
     auto pt_load = [&](int c) {      // every lane loads (clamped entry): no branch around a memory operation
         if constexpr (NV > 0) {
-            const int o = pt_src + c * CK;
+            const int o = pt_src + (c + cb) * CK;
             pr0 = *reinterpret_cast<const float4*>((MODE == IN_LAYERNORM ? p.ln_g : p.inA) + o);
             if constexpr (NV > 1) pr1 = *reinterpret_cast<const float4*>(p.inB + o);
             if constexpr (NV > 2) pr2 = *reinterpret_cast<const float4*>(p.inE + o);
@@ -178,7 +183,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
 
-    const int ntaps = NTAPS ? NTAPS : p.KH * p.KW, nchunks = p.Cin / CK, nit = ntaps * nchunks;
+    const int ntaps = NTAPS ? NTAPS : p.KH * p.KW, nchunks_tot = p.Cin / CK;
+    const int nchunks = (NTAPS == 9 && p.ksplit > 1) ? min(p.kchunks, nchunks_tot - cb) : nchunks_tot, nit = ntaps * nchunks;
     __syncthreads();                 // tables and the parameter table of slice 0 visible
 
     // per-thread staging items: item i = tid + NT*j = (pixel i / IPP, channels 8*(i % IPP)..+7).  NT is a
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
     auto w_load = [&](auto set, int c, int tap) {
         if (ABL(256)) return;
         constexpr int S = decltype(set)::value;
-        const char* wsrc = wbase + ((size_t)(tap * nchunks + c) * p.CoutPad + t.n0) * ROWB;
+        const char* wsrc = wbase + ((size_t)(tap * nchunks_tot + c + cb) * p.CoutPad + t.n0) * ROWB;
         if constexpr (S == 0) { HD_WLOAD(w, 0) HD_WLOAD(w, 1) HD_WLOAD(w, 2) HD_WLOAD(w, 3) }
         else if constexpr (S == 1) { HD_WLOAD(v, 0) HD_WLOAD(v, 1) HD_WLOAD(v, 2) HD_WLOAD(v, 3) }
         else { HD_WLOAD(u, 0) HD_WLOAD(u, 1) HD_WLOAD(u, 2) HD_WLOAD(u, 3) }
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
         *reinterpret_cast<uint4*>(d + 2 * CK) = lo;
     };
     auto slice_src = [&](int c, const float*& src, int& Csrc) {  // channel-concatenated input: two tensors
-        const int cc = c * CK;
+        const int cc = (c + cb) * CK;
         if (cc < p.C0) { src = p.in0 + cc + q8; Csrc = p.C0; } else { src = p.in1 + (cc - p.C0) + q8; Csrc = p.C1; }
     };
     auto mfma_cluster = [&](const char* Xc, const char* Wb, int tapoff) {
@@ -447,7 +453,7 @@ static int launch_one(K kernel, const char* name, ConvLaunch& L, hipStream_t st,
     }
     const ConvKArgs& k = L.k;
     const int mtiles = ((k.B + k.TB - 1) / k.TB) * k.tiles_y * k.tiles_x;
-    dim3 grid((unsigned)(mtiles * k.ntiles_n));
+    dim3 grid((unsigned)(mtiles * k.ntiles_n), (unsigned)(k.ksplit > 1 ? k.ksplit : 1));
     conv_prof_begin(L, name, st);
     hipLaunchKernelGGL(kernel, grid, dim3(nthreads), L.lds, st, L.k);
     conv_prof_end(st);

@@ -22,6 +22,8 @@ struct ConvKArgs {
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     const float* ep_ln_g; unsigned long long w_bstride; float* ln_stats_out;
     float* out; float* gn_part; int gn_slots;
+    int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
+    unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
     int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };

@@ -175,7 +175,42 @@ static bool gn_in_epilogue(const ConvPlan& pl) {
     return pl.g.TB == 1 || (pl.g.TB == 2 && pl.g.TH * pl.g.TW == 64 && pl.BM == 128);
 }
 
+// Split-K for 3x3 convolutions on tiny feature maps: a 5x5 or 10x10 map gives a handful of M tiles with K in the
+// thousands -- 100 workgroups on 256 CUs, each running 150-300 K slices in sequence.  Four K ranges per tile
+// (grid.y) write raw partial sums that splitk_reduce_kernel adds in a fixed order (+ bias).  The rule looks at the map
+// size only, never at the batch, so results do not depend on how many tiles are sampled together.  8x8 maps are left alone:
+// at 256 tiles they already give 512 workgroups (the headline workload), and one rule has to serve every batch.
+int conv_splitk(const ConvArgs& a) {
+    static const int forced = getenv("HICDIFF_SPLITK") ? atoi(getenv("HICDIFF_SPLITK")) : -1;
+    if (forced == 0) return 1;
+    if (a.precision != HD_PREC_BF16X3 || !a.cw.wsplit || a.cw.KH != 3 || a.cw.KW != 3 || a.stride != 1 || a.upsample || a.ep != 0 || a.w_bstride ||
+        (a.in_mode != IN_NONE && a.in_mode != IN_AFFINE_SILU))
+        return 1;
+    const int HW = a.H * a.W, nch = (a.C0 + a.C1) / a.cw.ck;
+    if (a.cw.ck != 32 || nch < 8 || !(HW < 64 || (HW > 64 && HW <= 128))) return 1;
+    const int want = forced > 0 ? forced : 4;
+    const int kchunks = (nch + want - 1) / want;
+    return (nch + kchunks - 1) / kchunks;          // every split non-empty
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t n4, const float* __restrict__ bias, int Cout,
+                                                            float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float4 s = reinterpret_cast<const float4*>(ws)[i];
+    for (int k = 1; k < nsplit; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)k * n4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % Cout);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+}
+
 int conv_gn_slots(const ConvArgs& a) {
+    if (conv_splitk(a) > 1) return 0;             // the partial sums are not final in the convolution's epilogue
     const ConvPlan pl = plan_conv(a);
     if (!gn_in_epilogue(pl)) return 0;
     return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW);
@@ -194,6 +229,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
     k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride; k.ln_stats_out = a.ln_stats_out;
     k.out = a.out;
+    k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
     static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;
@@ -225,6 +261,22 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
     if (pl.fast && pl.pt_n4 > 256) { hd_set_error("conv: loader-parameter table needs more than 256 entries per vector"); return -1; }
     if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }
+    const int ks = a.splitk_ws ? conv_splitk(a) : 1;
+    if (ks > 1) {
+        const int nch = k.Cin / pl.ck;
+        k.ksplit = ks; k.kchunks = (nch + ks - 1) / ks;
+        k.split_stride = (unsigned long long)a.B * a.H * a.W * k.Cout;
+        k.out = a.splitk_ws; k.bias = nullptr; k.gn_part = nullptr; k.gn_slots = 0;
+        if (gn_slots_out) *gn_slots_out = 0;
+        if (k.Cout != k.CoutPad) { hd_set_error("conv: split-K needs Cout a multiple of 64"); return -1; }
+        const int rc = launch_conv_bf16x3(L, st);
+        if (rc) return rc;
+        const size_t n4 = (size_t)k.split_stride / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a.splitk_ws, ks, n4, a.cw.bias, k.Cout, a.out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { hd_set_error(std::string("splitk_reduce: ") + hipGetErrorString(e)); return -3; }
+        return 0;
+    }
     return pl.fast ? launch_conv_bf16x3(L, st) : launch_conv_f32(L, st);
 }
 

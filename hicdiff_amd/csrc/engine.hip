@@ -365,9 +365,16 @@ static int probe(Run& r, const std::string& label, const Act& a) {
 }
 
 static int run_conv(Run& r, ConvArgs& a) {
-    if (r.dry) return 0;
     a.precision = r.c->precision;
-    return launch_conv(a, r.st, nullptr);
+    // the dry run sizes the workspace for either arithmetic (hd_set_precision may switch later): plan the split as the fast path would
+    ConvArgs probe = a; probe.precision = HD_PREC_BF16X3;
+    const int ks = conv_splitk(probe);
+    float* ws = nullptr;
+    if (ks > 1) HD_TRY(r.alloc((size_t)ks * a.B * a.H * a.W * a.cw.Cout, &ws));
+    a.splitk_ws = ws;
+    const int rc = r.dry ? 0 : launch_conv(a, r.st, nullptr);
+    if (ws) r.free(ws);          // stream order: whatever reuses the block runs after the reduce kernel
+    return rc;
 }
 
 // GroupNorm'd conv of the UNet: conv (+ fused per-channel partial sums when the tile geometry allows)

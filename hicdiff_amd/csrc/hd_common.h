@@ -65,6 +65,8 @@ struct ConvArgs {
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
     // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
     float* gn_part = nullptr;
+    // split-K workspace (conv_splitk(a) * B*H*W*Cout floats) for the convolutions the planner splits; null: never split
+    float* splitk_ws = nullptr;
     int precision = HD_PREC_F32;
 };
 
@@ -87,6 +89,7 @@ int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes
 
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
+int conv_splitk(const ConvArgs& a);    // K splits the planner wants for this convolution (1: none); a.precision must be set
 int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials would use (0: not fusable)
 
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
