@@ -16,7 +16,7 @@ class Adam:
             raise NotImplementedError("the reference trains with plain Adam (train.py:111)")
         self.params = [p for p in params]
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
-        self.state = {}            # trainer -> (m, v, step)
+        self.state = {}            # eps-network module -> (m, v, step); survives a re-sized trainer (ragged last batch)
         self.param_groups = [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps}]
 
     def zero_grad(self, set_to_none=True):
@@ -43,8 +43,8 @@ class Adam:
                 g = tr.grad_view(i)
                 if p.grad.data_ptr() != g.data_ptr():
                     g.copy_(p.grad)
-            m, v, k = self.state.get(tr, (None, None, 0))
-            if m is None:
+            m, v, k = self.state.get(tr.model, (None, None, 0))
+            if m is None or m.numel() != tr.flat.numel() or m.device != tr.flat.device:
                 m, v = torch.zeros_like(tr.flat), torch.zeros_like(tr.flat)
             k += 1
             scale = 1.0
@@ -58,5 +58,5 @@ class Adam:
                                       C.c_void_p(v.data_ptr()), tr.flat.numel(), lr, self.betas[0], self.betas[1], self.eps, k, scale, st)
             if rc != 0:
                 raise L.HdError(rc, "hd_adam_step failed")
-            self.state[tr] = (m, v, k)
+            self.state[tr.model] = (m, v, k)
             tr.weights_changed()

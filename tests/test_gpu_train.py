@@ -129,7 +129,7 @@ def test_train_loop_matches_oracle_loss_curve_and_serves_updated_weights():
         eps = torch.randn_like(x0)
         ol, og = OTR.loss_and_grads(sd, cfg, buf, x0.cpu(), t.cpu(), eps.cpu(), lq.cpu(), "l2")
         OTR.adam_step(sd, og, om, ov, step, lr=2e-4)
-        assert abs(float(loss) - float(ol)) <= 2e-3 * float(ol), step
+        assert abs(float(loss.detach()) - float(ol)) <= 2e-3 * float(ol), step
     d.eval()
     with torch.no_grad():
         after = d.model(x0, torch.full((B,), 10, device="cuda"), lq)
@@ -139,6 +139,40 @@ def test_train_loop_matches_oracle_loss_curve_and_serves_updated_weights():
     fresh.load_state_dict(d.model.state_dict())
     with torch.no_grad():
         assert torch.equal(fresh(x0, torch.full((B,), 10, device="cuda"), lq), after)
+
+
+def test_train_ragged_batch_keeps_adam_state():
+    """A smaller last batch re-sizes the trainer (new saved-activation buffers, parameters re-seated); Adam's moments and step
+    count belong to the network and carry over: the run follows the oracle's Adam run on the same draws, not one whose state
+    was reset when the batch size changed."""
+    from hicdiff_amd.optim import Adam
+    from oracle import diffusion as OD, train as OTR
+    d = _diffusion("cond", 1, 16)
+    d.train()
+    opt = Adam(d.parameters(), lr=1e-3)
+    sd, cfg = _oracle_sd("cond", 1)
+    buf = OD.diffusion_buffers("linear", 1000)
+    zeros = lambda: {k: torch.zeros_like(v) for k, v in sd.items()}
+    keep, (km, kv) = {k: v.clone() for k, v in sd.items()}, (zeros(), zeros())
+    reset, (rm, rv), rstep = {k: v.clone() for k, v in sd.items()}, (zeros(), zeros()), 0
+    for step, B in enumerate((4, 4, 3, 4), start=1):
+        x0, lq = tiles(60 + step, B, 16), tiles(70 + step, B, 16)
+        gen = torch.Generator().manual_seed(step)
+        t, eps = torch.randint(0, 1000, (B,), generator=gen), torch.randn(x0.shape, generator=gen)
+        loss = d.p_losses([lq.cuda(), x0.cuda()], t.cuda(), eps.cuda())
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        ol, og = OTR.loss_and_grads(keep, cfg, buf, x0, t, eps, lq, "l2")
+        OTR.adam_step(keep, og, km, kv, step, lr=1e-3)
+        assert abs(float(loss.detach()) - float(ol)) <= 2e-3 * float(ol), step
+        if B != 4 or step == 4:                             # what a per-trainer state would do: forget the moments at every re-size
+            (rm, rv), rstep = (zeros(), zeros()), 0
+        rstep += 1
+        _, rg = OTR.loss_and_grads(reset, cfg, buf, x0, t, eps, lq, "l2")
+        OTR.adam_step(reset, rg, rm, rv, rstep, lr=1e-3)
+    dist = lambda ref: sum(float((p.detach().cpu() - ref[k]).pow(2).sum()) for k, p in d.model.named_parameters()) ** 0.5
+    assert dist(keep) < 0.25 * dist(reset), (dist(keep), dist(reset))
 
 
 def test_train_errors():
