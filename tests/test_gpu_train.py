@@ -141,6 +141,34 @@ def test_train_loop_matches_oracle_loss_curve_and_serves_updated_weights():
         assert torch.equal(fresh(x0, torch.full((B,), 10, device="cuda"), lq), after)
 
 
+def test_train_full_network_properties():
+    """Size-independent properties on the full 32-block network at 64x64 tiles: the step repeats bit for bit, and the batch
+    gradient is the mean of its halves' gradients (the loss is a mean over samples; tiles never interact)."""
+    d = _diffusion("cond", 32, 64)
+    d.train()
+    B = 8
+    x0, lq = tiles(81, B, 64).cuda(), tiles(82, B, 64).cuda()
+    gen = torch.Generator().manual_seed(9)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()
+
+    def grads(sl):
+        for p in d.model.parameters():
+            p.grad = None
+        loss = d.p_losses([lq[sl], x0[sl]], t[sl], eps[sl])
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in d.model.named_parameters()}
+
+    l_all, g_all = grads(slice(0, B))
+    l_again, g_again = grads(slice(0, B))
+    assert l_all == l_again and all(torch.equal(g_all[k], g_again[k]) for k in g_all)
+    l_a, g_a = grads(slice(0, B // 2))
+    l_b, g_b = grads(slice(B // 2, B))
+    assert abs(l_all - 0.5 * (l_a + l_b)) <= 1e-5 * l_all
+    for k in g_all:
+        assert rel_err(g_all[k], 0.5 * (g_a[k] + g_b[k])) <= 2e-4, k
+    assert all(torch.isfinite(v).all() for v in g_all.values())
+
+
 def test_train_ragged_batch_keeps_adam_state():
     """A smaller last batch re-sizes the trainer (new saved-activation buffers, parameters re-seated); Adam's moments and step
     count belong to the network and carry over: the run follows the oracle's Adam run on the same draws, not one whose state
