@@ -16,6 +16,7 @@ HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
 HD_PRECISION_F32, HD_PRECISION_BF16X3 = 0, 1
+HD_TRAIN_PREC_BF16 = 2
 HD_PROFILE_MAX_ROWS = 96
 
 
@@ -75,6 +76,7 @@ SYMBOLS = {
     "hd_train_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),
     "hd_train_destroy": (None, [_P]),
     "hd_train_last_error": (C.c_char_p, [_P]),
+    "hd_train_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_train_param_count": (C.c_int, [_P, _P]),
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "hd_train_loss_backward": (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 3 + [C.c_int, _P, _P]),

@@ -22,7 +22,7 @@ def _ptr(t):
 class NativeTrainer:
     """Flat parameter / gradient storage of one eps-network plus the C trainer sized for (B, S)."""
 
-    def __init__(self, model, B: int, S: int):
+    def __init__(self, model, B: int, S: int, precision: str = "bf16x3"):
         p0 = next(model.parameters())
         if p0.device.type != "cuda":
             raise RuntimeError("hicdiff_amd trains on MI355X (HIP) tensors only; there is no CPU fallback")
@@ -36,6 +36,11 @@ class NativeTrainer:
             if rc == L.HD_EINVAL:
                 raise NotImplementedError(msg or "native training is not available for this network")
             raise L.HdError(rc, msg)
+        if precision not in ("bf16x3", "bf16"):
+            raise ValueError("training precision is 'bf16x3' (default, fp32-equivalent products) or 'bf16'")
+        self.precision = precision
+        if precision == "bf16":
+            self.lib.hd_train_set_precision(self.h, L.HD_TRAIN_PREC_BF16)
         total = C.c_longlong()
         n = self.lib.hd_train_param_count(self.h, C.byref(total))
         self.slots = []
@@ -131,11 +136,15 @@ class _NativeLoss(torch.autograd.Function):
 
 
 def trainer_for(model, B: int, S: int) -> NativeTrainer:
+    """The network's trainer, re-created when the batch shape, the device or the requested arithmetic changed.  The arithmetic is
+    `model.train_precision` ('bf16x3' | 'bf16') if set, else the environment's HICDIFF_TRAIN_PRECISION, else 'bf16x3'."""
+    import os
+    precision = getattr(model, "train_precision", None) or os.environ.get("HICDIFF_TRAIN_PRECISION", "bf16x3")
     tr = model.__dict__.get("_hd_trainer")
-    if tr is None or (tr.B, tr.S) != (B, S) or tr.device != next(model.parameters()).device or not tr.still_seated():
+    if tr is None or (tr.B, tr.S) != (B, S) or tr.device != next(model.parameters()).device or not tr.still_seated() or tr.precision != precision:
         if tr is not None:
             for p in tr.params:
                 p.grad = None
-        tr = NativeTrainer(model, B, S)
+        tr = NativeTrainer(model, B, S, precision)
         model.__dict__["_hd_trainer"] = tr
     return tr

@@ -100,8 +100,9 @@ __device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
 
 // WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread;
 // NTAPS = 9: 3x3 filter, taps unrolled; NTAPS = 0: any filter (1x1, 2x2 stride 2, ...), taps in a loop.
-template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+// PLAIN: one bf16 MFMA per product (hi x hi only) -- the optional bf16 arithmetic of the training step; the staging is unchanged.
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
+__device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = 4 * CK + 16, ROWB = 4 * CK;
     constexpr int KS = CK / 16;                        // k16 MFMA steps per slab
@@ -298,20 +299,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
             for (int tm = 0; tm < TM; ++tm) {
                 const char* a = Xc + aoff[tm] + tapoff + s * 32;
                 ah[tm] = *reinterpret_cast<const bf16x8*>(a);
-                al[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
+                if constexpr (!PLAIN) al[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
             }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const char* b = Wb + boff[tn] + s * 32;
                 bh[tn] = *reinterpret_cast<const bf16x8*>(b);
-                bl[tn] = *reinterpret_cast<const bf16x8*>(b + 2 * CK);
+                if constexpr (!PLAIN) bl[tn] = *reinterpret_cast<const bf16x8*>(b + 2 * CK);
             }
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) {
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    if constexpr (!PLAIN) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                    }
                     acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
                 }
         }
@@ -440,6 +443,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKAr
 #undef HD_WLOAD
 #undef HD_WSTORE
     conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(ptab));
+}
+
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, false>(p);
+}
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(ConvKArgs p) {
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, true>(p);
 }
 
 template <typename K>

@@ -230,6 +230,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride; k.ln_stats_out = a.ln_stats_out;
     k.out = a.out;
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
+    k.plain = a.plain_bf16;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
     static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;

@@ -67,6 +67,7 @@ struct ConvArgs {
     float* gn_part = nullptr;
     // split-K workspace (conv_splitk(a) * B*H*W*Cout floats) for the convolutions the planner splits; null: never split
     float* splitk_ws = nullptr;
+    int plain_bf16 = 0;               // with precision == HD_PREC_BF16X3: drop the two correction products where a plain-bf16 variant exists (training option)
     int precision = HD_PREC_F32;
 };
 

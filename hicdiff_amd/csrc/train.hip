@@ -38,6 +38,7 @@ int check_launch(const char* what) {
 // recomputed instead of stored).  colpart (optional): per-row channel sums for the bias gradient.
 // One workgroup per image row: float4 loads of four channels per thread on the way in, LDS transpose, then 16-byte stores of
 // 8 pixels per lane on the way out (8 lanes cover a channel's 64-pixel row segment).
+template <bool PLAIN>      // PLAIN: hi image only (the optional bf16 arithmetic)
 __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
                                                       const float* __restrict__ film, int film_bs, float* __restrict__ colpart) {
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
                 const __bf16 hh = (__bf16)e[j];
                 const __bf16 ll = (__bf16)(e[j] - (float)hh);
                 sh_hi[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, hh);
-                sh_lo[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, ll);
+                if constexpr (!PLAIN) sh_lo[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, ll);
             }
         }
         csum[pgp][c0] = sum.x; csum[pgp][c0 + 1] = sum.y; csum[pgp][c0 + 2] = sum.z; csum[pgp][c0 + 3] = sum.w;
@@ -80,9 +81,12 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
         for (int c = tid >> 3; c < C; c += 32) {
             const uint2* ph = reinterpret_cast<const uint2*>(sh_hi + c * PITCH + xg * 8);
             const uint2* pl = reinterpret_cast<const uint2*>(sh_lo + c * PITCH + xg * 8);
-            const uint2 h0 = ph[0], h1 = ph[1], l0 = pl[0], l1 = pl[1];
+            const uint2 h0 = ph[0], h1 = ph[1];
             *reinterpret_cast<uint4*>(hi + (size_t)c * ld + kbase) = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            *reinterpret_cast<uint4*>(lo + (size_t)c * ld + kbase) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            if constexpr (!PLAIN) {
+                const uint2 l0 = pl[0], l1 = pl[1];
+                *reinterpret_cast<uint4*>(lo + (size_t)c * ld + kbase) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
         }
     }
 }
@@ -104,6 +108,7 @@ __device__ __forceinline__ uint4 shift_next(const uint4& c, unsigned nextx) {   
                       __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(nextx, c.w, 16));
 }
 
+template <bool PLAIN>      // PLAIN: hi x hi only -- no lo images are loaded, staged or multiplied
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
                                                             const unsigned short* __restrict__ Ghi, const unsigned short* __restrict__ Glo,
                                                             size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int F,
@@ -140,9 +145,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
 #define HD_LD(p, j, K) (*reinterpret_cast<const uint4*>((p) + (size_t)(j) * 32 * ld + (K)))
 #define HD_LG(j, K) (*reinterpret_cast<const uint4*>(pg##j + (K)))
 #define HD_GLOAD(K)                                                                                  \
-    rAh0 = HD_LD(pAh, 0, K); rAl0 = HD_LD(pAl, 0, K); rAh1 = HD_LD(pAh, 1, K); rAl1 = HD_LD(pAl, 1, K); \
-    rAh2 = HD_LD(pAh, 2, K); rAl2 = HD_LD(pAl, 2, K); rAh3 = HD_LD(pAh, 3, K); rAl3 = HD_LD(pAl, 3, K); \
-    rG0 = HD_LG(0, K); rG1 = HD_LG(1, K); rG2 = HD_LG(2, K); rG3 = HD_LG(3, K); rG4 = HD_LG(4, K);
+    rAh0 = HD_LD(pAh, 0, K); rAh1 = HD_LD(pAh, 1, K); rAh2 = HD_LD(pAh, 2, K); rAh3 = HD_LD(pAh, 3, K);     \
+    if constexpr (!PLAIN) { rAl0 = HD_LD(pAl, 0, K); rAl1 = HD_LD(pAl, 1, K); rAl2 = HD_LD(pAl, 2, K); rAl3 = HD_LD(pAl, 3, K); } \
+    rG0 = HD_LG(0, K); rG1 = HD_LG(1, K); rG2 = HD_LG(2, K);                                                \
+    if constexpr (!PLAIN) { rG3 = HD_LG(3, K); rG4 = HD_LG(4, K); }
 #define HD_STA(m, j, r) *reinterpret_cast<uint4*>(sA[m] + aloff + (j) * 32 * PA) = r
 #define HD_STG(j, r) *reinterpret_cast<uint4*>(lg##j) = r
     f32x16 acc[2][3];
@@ -155,8 +161,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     HD_GLOAD(0)
     for (int s = 0; s < nslices; ++s) {
         HD_STA(0, 0, rAh0); HD_STA(0, 1, rAh1); HD_STA(0, 2, rAh2); HD_STA(0, 3, rAh3);
-        HD_STA(1, 0, rAl0); HD_STA(1, 1, rAl1); HD_STA(1, 2, rAl2); HD_STA(1, 3, rAl3);
-        HD_STG(0, rG0); HD_STG(1, rG1); HD_STG(2, rG2); HD_STG(3, rG3); HD_STG(4, rG4);
+        if constexpr (!PLAIN) { HD_STA(1, 0, rAl0); HD_STA(1, 1, rAl1); HD_STA(1, 2, rAl2); HD_STA(1, 3, rAl3); }
+        HD_STG(0, rG0); HD_STG(1, rG1); HD_STG(2, rG2);          // chunks 0..767: all of hi (and, harmlessly, the first lo chunks)
+        if constexpr (!PLAIN) { HD_STG(3, rG3); HD_STG(4, rG4); }
         __syncthreads();
         { const size_t kn = (size_t)min(s + 1, nslices - 1) * KS; HD_GLOAD(kn) }
 #pragma unroll
@@ -166,23 +173,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
             for (int t = 0; t < 2; ++t) {
                 const int ro = (wm * 64 + t * 32 + l31) * PA + ks * 32 + half * 16;
                 ah[t] = *reinterpret_cast<const bf16x8*>(sA[0] + ro);
-                al[t] = *reinterpret_cast<const bf16x8*>(sA[1] + ro);
+                if constexpr (!PLAIN) al[t] = *reinterpret_cast<const bf16x8*>(sA[1] + ro);
             }
             const int go = (wn * 32 + l31) * PG + ks * 32 + half * 16 + 16;                 // element k sits at byte (k - k0 + 8) * 2
-            const uint4 ch = *reinterpret_cast<const uint4*>(sG[0] + go), cl = *reinterpret_cast<const uint4*>(sG[1] + go);
-            const unsigned ph = *reinterpret_cast<const unsigned*>(sG[0] + go - 4), pl = *reinterpret_cast<const unsigned*>(sG[1] + go - 4);
-            const unsigned nh = *reinterpret_cast<const unsigned*>(sG[0] + go + 16), nl = *reinterpret_cast<const unsigned*>(sG[1] + go + 16);
+            const uint4 ch = *reinterpret_cast<const uint4*>(sG[0] + go);
+            const unsigned ph = *reinterpret_cast<const unsigned*>(sG[0] + go - 4), nh = *reinterpret_cast<const unsigned*>(sG[0] + go + 16);
             bf16x8 bh[3], bl[3];
             // kx = 0 (dx = -1): G[k + 1 ...];  kx = 1: G[k ...];  kx = 2 (dx = +1): G[k - 1 ...]
-            bh[0] = __builtin_bit_cast(bf16x8, shift_next(ch, nh)); bl[0] = __builtin_bit_cast(bf16x8, shift_next(cl, nl));
-            bh[1] = __builtin_bit_cast(bf16x8, ch);                 bl[1] = __builtin_bit_cast(bf16x8, cl);
-            bh[2] = __builtin_bit_cast(bf16x8, shift_prev(ch, ph)); bl[2] = __builtin_bit_cast(bf16x8, shift_prev(cl, pl));
+            bh[0] = __builtin_bit_cast(bf16x8, shift_next(ch, nh));
+            bh[1] = __builtin_bit_cast(bf16x8, ch);
+            bh[2] = __builtin_bit_cast(bf16x8, shift_prev(ch, ph));
+            if constexpr (!PLAIN) {
+                const uint4 cl = *reinterpret_cast<const uint4*>(sG[1] + go);
+                const unsigned pl = *reinterpret_cast<const unsigned*>(sG[1] + go - 4), nl = *reinterpret_cast<const unsigned*>(sG[1] + go + 16);
+                bl[0] = __builtin_bit_cast(bf16x8, shift_next(cl, nl));
+                bl[1] = __builtin_bit_cast(bf16x8, cl);
+                bl[2] = __builtin_bit_cast(bf16x8, shift_prev(cl, pl));
+            }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
-                    acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[dx], acc[tm][dx], 0, 0, 0);
-                    acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[dx], acc[tm][dx], 0, 0, 0);
+                    if constexpr (!PLAIN) {
+                        acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[dx], acc[tm][dx], 0, 0, 0);
+                        acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[dx], acc[tm][dx], 0, 0, 0);
+                    }
                     acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[dx], acc[tm][dx], 0, 0, 0);
                 }
         }
@@ -465,7 +480,7 @@ struct hd_trainer {
     ConvW tail_fwd;
     float *wt_tmp = nullptr, *tail_flip = nullptr, *zero_bias = nullptr;
     // weight-gradient geometry and operands
-    int P = 0, splitK = 1;
+    int P = 0, splitK = 1, plain = 0;     // plain: bf16 products without the two correction terms (hd_train_set_precision)
     size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
     unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
     float *partial = nullptr, *colpart = nullptr, *ctmp = nullptr;
@@ -601,6 +616,13 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     return HD_OK;
 }
 
+int hd_train_set_precision(hd_trainer* t, int mode) {
+    if (!t || (mode != HD_PREC_BF16X3 && mode != 2)) return HD_EINVAL;
+    // switching back from plain bf16: the lo images hold stale zeros / old data only where the next rewrite overwrites them
+    t->plain = mode == 2 ? 1 : 0;
+    return HD_OK;
+}
+
 int hd_train_param_count(const hd_trainer* t, long long* total_floats) {
     if (!t) return HD_EINVAL;
     if (total_floats) *total_floats = (long long)t->nparams;
@@ -623,15 +645,19 @@ int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long
 static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st) {
     ConvArgs a;
     a.in0 = in; a.C0 = tr->F; a.B = tr->B; a.H = tr->S; a.W = tr->S; a.IH = tr->S; a.IW = tr->S; a.stride = 1; a.pad = 1; a.cw = w; a.out = out;
-    a.ep = ep; a.alpha = alpha; a.res = res; a.precision = HD_PREC_BF16X3;
+    a.ep = ep; a.alpha = alpha; a.res = res; a.precision = HD_PREC_BF16X3; a.plain_bf16 = tr->plain;
     return launch_conv(a, st, nullptr);
 }
 
 static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
     const int F = tr->F, S = tr->S;
-    hd_prof_begin("wg_prep_kernel", 0.0, (double)tr->B * S * S * F * (4.0 + 4.0), st);          // fp32 in, bf16 hi + lo out
-    hipLaunchKernelGGL(wg_prep_kernel, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
-                       gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
+    hd_prof_begin("wg_prep_kernel", 0.0, (double)tr->B * S * S * F * (4.0 + (tr->plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
+    if (tr->plain)
+        hipLaunchKernelGGL(wg_prep_kernel<true>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
+                           gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
+    else
+        hipLaunchKernelGGL(wg_prep_kernel<false>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
+                           gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
     conv_prof_end(st);
     return check_launch("wg_prep");
 }
@@ -642,9 +668,13 @@ static int wgrad(hd_trainer* tr, float scale, bool accumulate, float* dW, hipStr
     static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
     // algorithmic figures: 9 taps x F x F outputs over the B*S*S real pixels (3 MFMA flops per product are the kernel's business);
     // bytes: both operand images once (hi + lo) + the partials
-    hd_prof_begin("wgrad_gemm_kernel", 2.0 * 9 * F * F * (double)tr->B * tr->S * tr->S, 2.0 * 2 * 2 * F * (double)tr->Kpad + 4.0 * tr->splitK * 9 * F * F, st);
-    hipLaunchKernelGGL(wgrad_gemm_kernel, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
-                       tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
+    hd_prof_begin(tr->plain ? "wgrad_gemm_kernel<true>" : "wgrad_gemm_kernel<false>", 2.0 * 9 * F * F * (double)tr->B * tr->S * tr->S, (tr->plain ? 1.0 : 2.0) * 2 * 2 * F * (double)tr->Kpad + 4.0 * tr->splitK * 9 * F * F, st);
+    if (tr->plain)
+        hipLaunchKernelGGL(wgrad_gemm_kernel<true>, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
+                           tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
+    else
+        hipLaunchKernelGGL(wgrad_gemm_kernel<false>, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
+                           tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
     conv_prof_end(st);
     if (check_launch("wgrad gemm")) return -3;
     const size_t per = (size_t)3 * F * 3 * F;

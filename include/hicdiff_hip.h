@@ -219,6 +219,13 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* arch, int 
 void hd_train_destroy(hd_trainer* t);
 const char* hd_train_last_error(const hd_trainer* t);
 
+/* Arithmetic of the 256-channel convolutions and of the weight-gradient GEMM: HD_PRECISION_BF16X3 (default: three bf16 MFMA products
+ * per fp32 product, the arithmetic of the parity tests) or HD_TRAIN_PREC_BF16 (one bf16 product, fp32 accumulate: the "bf16 compute,
+ * fp32 master weights" of mixed-precision training; gradients then carry bf16 rounding, ~1e-2 relative).  Master weights, gradients,
+ * Adam state, FiLM / time MLP and every elementwise step stay fp32 in both. */
+#define HD_TRAIN_PREC_BF16 2
+int hd_train_set_precision(hd_trainer* t, int mode);
+
 /* Number of parameter tensors; *total_floats = length of the flat arrays. */
 int hd_train_param_count(const hd_trainer* t, long long* total_floats);
 /* Slot i: state_dict key, offset in floats, shape (padded with 1s to 4 entries), rank. */
