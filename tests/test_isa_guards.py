@@ -58,21 +58,23 @@ def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
     (4.6x slower).  The GEMM's slice loop must have no scratch traffic and must issue its 13 loads of a slice back to back."""
     text = _asm("train.hip")
     kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S))
-    name = next(k for k in kernels if "wgrad_gemm_kernel" in k)
-    body = text[text.index(name + ":"):]
-    body = body[:body.index("s_endpgm")]
-    # the slice loop is the innermost loop: no scratch traffic inside it (a few address registers may spill around the outer
-    # row-shift loop, which runs three times)
-    inner = body[body.rindex("Depth=2"):]
-    inner = inner[:inner.index("s_cbranch")]
-    assert "scratch_" not in inner and inner.count("v_mfma") == 72
-    ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
-    runs, cur = [], 0
-    for op in ops:
-        if op.startswith("global_load_dwordx4"):
-            cur += 1
-        elif op.startswith("s_waitcnt") or op.startswith("scratch"):
-            runs.append(cur)
-            cur = 0
-    runs.append(cur)
-    assert max(runs) >= 13, f"longest run of global loads without a wait: {max(runs)}"
+    # two instantiations: <false> = split-bf16 x3 (72 MFMAs and 13 loads per slice), <true> = plain bf16 (24 MFMAs, 7 loads)
+    for tag, mfmas, loads in (("ILb0E", 72, 13), ("ILb1E", 24, 7)):
+        name = next(k for k in kernels if "wgrad_gemm_kernel" in k and tag in k)
+        body = text[text.index(name + ":"):]
+        body = body[:body.index("s_endpgm")]
+        # the slice loop is the innermost loop: no scratch traffic inside it (a few address registers may spill around the outer
+        # row-shift loop, which runs three times)
+        inner = body[body.rindex("Depth=2"):]
+        inner = inner[:inner.index("s_cbranch")]
+        assert "scratch_" not in inner and inner.count("v_mfma") == mfmas, (tag, inner.count("v_mfma"))
+        ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
+        runs, cur = [], 0
+        for op in ops:
+            if op.startswith("global_load_dwordx4"):
+                cur += 1
+            elif op.startswith("s_waitcnt") or op.startswith("scratch"):
+                runs.append(cur)
+                cur = 0
+        runs.append(cur)
+        assert max(runs) >= loads, f"{tag}: longest run of global loads without a wait: {max(runs)}"
