@@ -284,7 +284,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         if (it_pad[j]) { hi = make_uint4(0, 0, 0, 0); lo = hi; }   // zero padding is applied AFTER the transform
         char* d = xdst + it_dst[j];
         *reinterpret_cast<uint4*>(d) = hi;
-        *reinterpret_cast<uint4*>(d + 2 * CK) = lo;
+        if constexpr (!PLAIN) *reinterpret_cast<uint4*>(d + 2 * CK) = lo;      // (PLAIN: the lo half of the split is dead code)
     };
     auto slice_src = [&](int c, const float*& src, int& Csrc) {  // channel-concatenated input: two tensors
         const int cc = (c + cb) * CK;
