@@ -228,8 +228,14 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [3][F][3F]
     const size_t per = (size_t)3 * F * 3 * F;
     if (i >= per) return;
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * per + i];
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // independent chains: see sum_rows_kernel
+    int sp = 0;
+    for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += partial[(size_t)(sp + j) * per + i];
+    }
+    for (; sp < nsplit; ++sp) a[sp & 7] += partial[(size_t)sp * per + i];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     const int n = (int)(i % (3 * F)), ci = (int)((i / (3 * F)) % F), ky = (int)(i / ((size_t)3 * F * F));
     const int kx = n / F, co = n % F;
     float* d = dW + (((size_t)co * F + ci) * 3 + ky) * 3 + kx;
@@ -293,8 +299,15 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
     const int col = blockIdx.x * 256 + threadIdx.x, bt = blockIdx.y;
     if (col >= ncols) return;
     const float* p = in + (size_t)bt * nrows * ncols + col;
-    float s = 0.f;
-    for (int r = 0; r < nrows; ++r) s += p[(size_t)r * ncols];
+    // eight independent partial sums: the loads of a serial chain would each wait out the full memory latency
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[(size_t)(r + j) * ncols];
+    }
+    for (; r < nrows; ++r) a[r & 7] += p[(size_t)r * ncols];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     float* d = out + (size_t)bt * ncols + col;
     *d = (accumulate ? *d : 0.f) + scale * s;
 }
