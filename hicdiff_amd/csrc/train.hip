@@ -41,26 +41,37 @@ int check_launch(const char* what) {
 template <bool PLAIN>      // PLAIN: hi image only (the optional bf16 arithmetic)
 __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
-                                                      const float* __restrict__ film, int film_bs, float* __restrict__ colpart) {
+                                                      const float* __restrict__ film, int film_bs, float* __restrict__ colpart, int row0,
+                                                      const float* __restrict__ affB) {
+    // mode 0: raw; mode 1: silu(v * (film[b][c] + 1) + film[b][film_bs - C + c]) (film_bs == C: no scale) -- the hicedrn block;
+    // mode 2: silu(v * film[b*film_bs + c] + affB[b*film_bs + c]) -- a GroupNorm'd, FiLM'd activation given as a per-(sample, channel) affine.
+    // grid.y walks the channels in chunks of 256; row0 = first image row this tensor's channels go to (channel-concatenated inputs).
     constexpr int PITCH = 68;                                  // ushorts per channel row: 136 B, 8-byte aligned, 2-way conflicts at most
     __shared__ __attribute__((aligned(16))) unsigned short sh_hi[256 * PITCH], sh_lo[256 * PITCH];
     __shared__ float csum[4][256];
-    const int b = blockIdx.x / H, y = blockIdx.x % H, tid = threadIdx.x;
+    const int b = blockIdx.x / H, y = blockIdx.x % H, tid = threadIdx.x, cbase = blockIdx.y * 256;
+    const int W8 = (W + 7) & ~7;
     // thread = (channel quad, pixel group): float4 loads (1 KB per wave), pixels pg, pg + 4, ...
-    const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4;
-    if (c0 < C) {
+    const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4, cg = cbase + c0;
+    if (cg < C) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f);
         if (mode == 1) {                                       // film row: [scale | shift] (film_bs == 2C) or [shift] alone (SR3, film_bs == C)
             if (film_bs == 2 * C) {
-                sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + c0);
+                sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + cg);
                 sc.x += 1.f; sc.y += 1.f; sc.z += 1.f; sc.w += 1.f;
             }
-            shf = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + (film_bs - C) + c0);
+            shf = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + (film_bs - C) + cg);
+        } else if (mode == 2) {
+            sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + cg);
+            shf = *reinterpret_cast<const float4*>(affB + (size_t)b * film_bs + cg);
         }
-        const float* src = in + ((size_t)(b * H + y) * W) * C + c0;
-        for (int x = pgp; x < W; x += 4) {
-            float4 v = *reinterpret_cast<const float4*>(src + (size_t)x * C);
-            if (mode == 1) { v.x = silu_f(v.x * sc.x + shf.x); v.y = silu_f(v.y * sc.y + shf.y); v.z = silu_f(v.z * sc.z + shf.z); v.w = silu_f(v.w * sc.w + shf.w); }
+        const float* src = in + ((size_t)(b * H + y) * W) * C + cg;
+        for (int x = pgp; x < W8; x += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // columns W .. W8-1 of the last 8-pixel group stay zero (they are padding)
+            if (x < W) {
+                v = *reinterpret_cast<const float4*>(src + (size_t)x * C);
+                if (mode) { v.x = silu_f(v.x * sc.x + shf.x); v.y = silu_f(v.y * sc.y + shf.y); v.z = silu_f(v.z * sc.z + shf.z); v.w = silu_f(v.w * sc.w + shf.w); }
+            }
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -74,18 +85,19 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
         csum[pgp][c0] = sum.x; csum[pgp][c0 + 1] = sum.y; csum[pgp][c0 + 2] = sum.z; csum[pgp][c0 + 3] = sum.w;
     }
     __syncthreads();
-    if (colpart && tid < C) colpart[(size_t)blockIdx.x * C + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+    if (colpart && cbase + tid < C) colpart[(size_t)blockIdx.x * C + cbase + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
     const int xg = tid & 7;
     const size_t kbase = guard + ((size_t)b * (H + 1) + y + 1) * P + 8 + xg * 8;
-    if (xg * 8 < W) {
-        for (int c = tid >> 3; c < C; c += 32) {
+    if (xg * 8 < W8) {
+        for (int c = tid >> 3; c < 256 && cbase + c < C; c += 32) {
             const uint2* ph = reinterpret_cast<const uint2*>(sh_hi + c * PITCH + xg * 8);
             const uint2* pl = reinterpret_cast<const uint2*>(sh_lo + c * PITCH + xg * 8);
             const uint2 h0 = ph[0], h1 = ph[1];
-            *reinterpret_cast<uint4*>(hi + (size_t)c * ld + kbase) = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            const size_t o = (size_t)(row0 + cbase + c) * ld + kbase;
+            *reinterpret_cast<uint4*>(hi + o) = make_uint4(h0.x, h0.y, h1.x, h1.y);
             if constexpr (!PLAIN) {
                 const uint2 l0 = pl[0], l1 = pl[1];
-                *reinterpret_cast<uint4*>(lo + (size_t)c * ld + kbase) = make_uint4(l0.x, l0.y, l1.x, l1.y);
+                *reinterpret_cast<uint4*>(lo + o) = make_uint4(l0.x, l0.y, l1.x, l1.y);
             }
         }
     }
@@ -108,7 +120,7 @@ __device__ __forceinline__ uint4 shift_next(const uint4& c, unsigned nextx) {   
                       __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(nextx, c.w, 16));
 }
 
-template <bool PLAIN>      // PLAIN: hi x hi only -- no lo images are loaded, staged or multiplied
+template <bool PLAIN, bool ONE>      // PLAIN: hi x hi only -- no lo images are loaded, staged or multiplied.  ONE: 1x1 filter, centre tap only
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
                                                             const unsigned short* __restrict__ Ghi, const unsigned short* __restrict__ Glo,
                                                             size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int F,
@@ -125,7 +137,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     const int nt = inner % Ntiles, mt = inner / Ntiles;
     const size_t k0 = guard + (size_t)split * kchunk;
     const int nslices = (int)(kchunk / KS);
-    const int N = 3 * F;
+    constexpr int NDX = ONE ? 1 : 3;
+    const int N = NDX * F;
     // A: rows lrow + 32 j (j < 4), chunk lch.  G: 64 rows x 10 chunks x {hi, lo} = 1280 chunks, five per thread.
     const int lrow = tid >> 3, lch = tid & 7;
     const size_t aoff = (size_t)lrow * ld + lch * 8;
@@ -137,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     char* const lg##j = sG[wh##j] + row##j * PG + ch##j * 16;
     HD_GDEF(0) HD_GDEF(1) HD_GDEF(2) HD_GDEF(3) HD_GDEF(4)
 #undef HD_GDEF
-    for (int dyi = 0; dyi < 3; ++dyi) {
+    for (int dyi = ONE ? 1 : 0; dyi < (ONE ? 2 : 3); ++dyi) {
     const size_t ka = (size_t)((long)k0 + (long)(dyi - 1) * P);
     const unsigned short* pAh = Ahi + (size_t)mt * BM * ld + ka + aoff;
     const unsigned short* pAl = Alo + (size_t)mt * BM * ld + ka + aoff;
@@ -151,11 +164,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     if constexpr (!PLAIN) { rG3 = HD_LG(3, K); rG4 = HD_LG(4, K); }
 #define HD_STA(m, j, r) *reinterpret_cast<uint4*>(sA[m] + aloff + (j) * 32 * PA) = r
 #define HD_STG(j, r) *reinterpret_cast<uint4*>(lg##j) = r
-    f32x16 acc[2][3];
+    f32x16 acc[2][NDX];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 3; ++b)
+        for (int b = 0; b < NDX; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     HD_GLOAD(0)
@@ -180,20 +193,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
             const unsigned ph = *reinterpret_cast<const unsigned*>(sG[0] + go - 4), nh = *reinterpret_cast<const unsigned*>(sG[0] + go + 16);
             bf16x8 bh[3], bl[3];
             // kx = 0 (dx = -1): G[k + 1 ...];  kx = 1: G[k ...];  kx = 2 (dx = +1): G[k - 1 ...]
-            bh[0] = __builtin_bit_cast(bf16x8, shift_next(ch, nh));
-            bh[1] = __builtin_bit_cast(bf16x8, ch);
-            bh[2] = __builtin_bit_cast(bf16x8, shift_prev(ch, ph));
-            if constexpr (!PLAIN) {
-                const uint4 cl = *reinterpret_cast<const uint4*>(sG[1] + go);
-                const unsigned pl = *reinterpret_cast<const unsigned*>(sG[1] + go - 4), nl = *reinterpret_cast<const unsigned*>(sG[1] + go + 16);
-                bl[0] = __builtin_bit_cast(bf16x8, shift_next(cl, nl));
-                bl[1] = __builtin_bit_cast(bf16x8, cl);
-                bl[2] = __builtin_bit_cast(bf16x8, shift_prev(cl, pl));
+            if constexpr (ONE) {
+                bh[0] = __builtin_bit_cast(bf16x8, ch);
+                if constexpr (!PLAIN) bl[0] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sG[1] + go));
+            } else {
+                bh[0] = __builtin_bit_cast(bf16x8, shift_next(ch, nh));
+                bh[1] = __builtin_bit_cast(bf16x8, ch);
+                bh[2] = __builtin_bit_cast(bf16x8, shift_prev(ch, ph));
+                if constexpr (!PLAIN) {
+                    const uint4 cl = *reinterpret_cast<const uint4*>(sG[1] + go);
+                    const unsigned pl = *reinterpret_cast<const unsigned*>(sG[1] + go - 4), nl = *reinterpret_cast<const unsigned*>(sG[1] + go + 16);
+                    bl[0] = __builtin_bit_cast(bf16x8, shift_next(cl, nl));
+                    bl[1] = __builtin_bit_cast(bf16x8, cl);
+                    bl[2] = __builtin_bit_cast(bf16x8, shift_prev(cl, pl));
+                }
             }
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
+                for (int dx = 0; dx < NDX; ++dx) {
                     if constexpr (!PLAIN) {
                         acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[dx], acc[tm][dx], 0, 0, 0);
                         acc[tm][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[dx], acc[tm][dx], 0, 0, 0);
@@ -208,11 +226,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
 #undef HD_LG
 #undef HD_STA
 #undef HD_STG
-    float* out = partial + ((size_t)(split * 3 + dyi) * M) * N;
+    float* out = partial + ((size_t)(split * NDX + (ONE ? 0 : dyi)) * M) * N;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
+        for (int dx = 0; dx < NDX; ++dx)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * BM + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -222,12 +240,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     }
 }
 
-// dW[co][ci][ky][kx] (torch layout) (+)= scale * sum_split partial[split][ky][ci][kx*F + co]
-__global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ partial, int nsplit, int F, float scale, int accumulate,
-                                                        float* __restrict__ dW) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [3][F][3F]
-    const size_t per = (size_t)3 * F * 3 * F;
+// dW[co][ci][ky][kx] (torch layout, KT x KT taps, KT = 3 or 1) (+)= scale * sum_split partial[split][ky][ci (< Mpad)][kx*Cout + co]
+__global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ partial, int nsplit, int Cin, int Mpad, int Cout, int KT, float scale,
+                                                        int accumulate, float* __restrict__ dW) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [KT][Mpad][KT*Cout]
+    const size_t per = (size_t)KT * Mpad * KT * Cout;
     if (i >= per) return;
+    const int n = (int)(i % ((size_t)KT * Cout)), ci = (int)((i / ((size_t)KT * Cout)) % Mpad), ky = (int)(i / ((size_t)KT * Cout * Mpad));
+    if (ci >= Cin) return;                                             // zero rows that pad the activation image to 128
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // independent chains: see sum_rows_kernel
     int sp = 0;
     for (; sp + 8 <= nsplit; sp += 8) {
@@ -236,9 +256,8 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
     }
     for (; sp < nsplit; ++sp) a[sp & 7] += partial[(size_t)sp * per + i];
     const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-    const int n = (int)(i % (3 * F)), ci = (int)((i / (3 * F)) % F), ky = (int)(i / ((size_t)3 * F * F));
-    const int kx = n / F, co = n % F;
-    float* d = dW + (((size_t)co * F + ci) * 3 + ky) * 3 + kx;
+    const int kx = n / Cout, co = n % Cout;
+    float* d = dW + (((size_t)co * Cin + ci) * KT + ky) * KT + kx;
     *d = (accumulate ? *d : 0.f) + scale * s;
 }
 
@@ -478,6 +497,79 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }  // namespace
 
 // =====================================================================================================================
+// Weight gradient of a KT x KT (3 or 1), stride-1, same-padded convolution as a reusable component: one instance per map geometry
+// (B, H, W), because the zero padding of its operand images is positional.  rewrite() fills the activation image (gside == false;
+// channel-concatenated inputs are two calls with row0 = 0 and row0 = C0) or the gradient image; run() multiplies and reduces.
+struct Wgrad {
+    int B = 0, H = 0, W = 0, P = 0, splitK = 1, maxCin = 0, maxCout = 0;
+    size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
+    unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
+    float* partial = nullptr;
+    std::vector<void*> owned;
+    void destroy() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
+    bool init(int B_, int H_, int W_, int maxCin_, int maxCout_) {
+        B = B_; H = H_; W = W_; maxCin = (maxCin_ + 127) / 128 * 128; maxCout = maxCout_;
+        P = ((W + 7) & ~7) + 8;
+        const size_t K = ((size_t)B * (H + 1) + 1) * P;
+        // 8 tiles of 128 x 64 (x 3 taps) per split at 256 channels; 64 splits = 512 workgroups = one round at two per CU, 8 splits per XCD
+        const size_t max_split = getenv("HICDIFF_WG_SPLITK") ? (size_t)atoi(getenv("HICDIFF_WG_SPLITK")) : 64;
+        splitK = (int)std::max<size_t>(1, std::min<size_t>(max_split, K / 2048));
+        if (splitK >= 8) splitK &= ~7;
+        Kpad = (K + (size_t)64 * splitK - 1) / ((size_t)64 * splitK) * ((size_t)64 * splitK);
+        kchunk = Kpad / splitK;
+        guard = ((size_t)P + 72 + 63) / 64 * 64;                  // row shift (P) + one slice of read-ahead
+        ld = guard + Kpad + guard;
+        auto zalloc = [&](size_t bytes) -> void* {
+            void* p = nullptr;
+            if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+            if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+            owned.push_back(p);
+            return p;
+        };
+        a_hi = (unsigned short*)zalloc((size_t)maxCin * ld * 2); a_lo = (unsigned short*)zalloc((size_t)maxCin * ld * 2);
+        b_hi = (unsigned short*)zalloc((size_t)maxCout * ld * 2); b_lo = (unsigned short*)zalloc((size_t)maxCout * ld * 2);
+        partial = (float*)zalloc((size_t)splitK * 9 * maxCin * maxCout * sizeof(float));
+        return a_hi && a_lo && b_hi && b_lo && partial;
+    }
+    int rewrite(const float* in, int C, int row0, bool gside, int mode, const float* film, int film_bs, const float* affB, float* colpart, bool plain,
+                hipStream_t st) const {
+        hd_prof_begin("wg_prep_kernel", 0.0, (double)B * H * W * C * (4.0 + (plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
+        const dim3 grid(B * H, (C + 255) / 256);
+        if (plain)
+            hipLaunchKernelGGL(wg_prep_kernel<true>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
+                               film_bs, colpart, row0, affB);
+        else
+            hipLaunchKernelGGL(wg_prep_kernel<false>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
+                               film_bs, colpart, row0, affB);
+        conv_prof_end(st);
+        return check_launch("wg_prep");
+    }
+    // dW[Cout][Cin][KT][KT] (+)= scale * sum over pixels (activation image rows 0..Cin-1, gradient image rows 0..Cout-1)
+    int run(int Cin, int Cout, int KT, float scale, bool accumulate, float* dW, bool plain, hipStream_t st) const {
+        static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
+        const int Mt = (Cin + 127) / 128, Nt = Cout / 64, Mpad = Mt * 128;
+        if (Cout % 64 || Mpad > maxCin || Cout > maxCout || (KT != 1 && KT != 3)) { hd_set_error("wgrad: unsupported shape"); return -1; }
+        // algorithmic figures: KT*KT taps x Cin x Cout outputs over the B*H*W real pixels (3 MFMA flops per product are the kernel's business);
+        // bytes: both operand images once (hi + lo) + the partials
+        const char* name = KT == 1 ? (plain ? "wgrad_gemm_kernel<true, true>" : "wgrad_gemm_kernel<false, true>")
+                                   : (plain ? "wgrad_gemm_kernel<true>" : "wgrad_gemm_kernel<false>");
+        hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, (plain ? 1.0 : 2.0) * 2 * (Cin + Cout) * (double)Kpad + 4.0 * splitK * KT * KT * Cin * Cout, st);
+        const dim3 grid(Mt * Nt * splitK);
+#define HD_WG_LAUNCH(PLAIN_, ONE_)                                                                                          \
+        hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kchunk, splitK, Mt, Nt, Mpad, Cout, \
+                           partial, xcd_group)
+        if (KT == 1) { if (plain) HD_WG_LAUNCH(true, true); else HD_WG_LAUNCH(false, true); }
+        else { if (plain) HD_WG_LAUNCH(true, false); else HD_WG_LAUNCH(false, false); }
+#undef HD_WG_LAUNCH
+        conv_prof_end(st);
+        if (check_launch("wgrad gemm")) return -3;
+        const size_t per = (size_t)KT * Mpad * KT * Cout;
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, splitK, Cin, Mpad, Cout, KT, scale, accumulate ? 1 : 0, dW);
+        return check_launch("wg_reduce");
+    }
+};
+
+// =====================================================================================================================
 struct hd_trainer {
     hd_arch_desc arch{};
     int device = 0, B = 0, S = 0, F = 256, nres = 0, cin0 = 1, tdim = 1024, FW = 512;   // FW: FiLM row width (2F; F for SR3's additive form)
@@ -493,10 +585,9 @@ struct hd_trainer {
     ConvW tail_fwd;
     float *wt_tmp = nullptr, *tail_flip = nullptr, *zero_bias = nullptr;
     // weight-gradient geometry and operands
-    int P = 0, splitK = 1, plain = 0;     // plain: bf16 products without the two correction terms (hd_train_set_precision)
-    size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
-    unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
-    float *partial = nullptr, *colpart = nullptr, *ctmp = nullptr;
+    int plain = 0;                        // bf16 products without the two correction terms (hd_train_set_precision)
+    Wgrad wg;                             // operand images + partials of the 256 -> 256 weight gradients
+    float *colpart = nullptr, *ctmp = nullptr;
     // activations
     std::vector<float*> X, U;             // X[0..nres], U[0..nres-1]
     float *Y = nullptr, *out = nullptr, *xt = nullptr, *dout = nullptr, *g0 = nullptr, *g1 = nullptr, *g2 = nullptr, *per = nullptr;
@@ -537,6 +628,7 @@ const char* hd_train_last_error(const hd_trainer* t) { return t ? t->err.c_str()
 void hd_train_destroy(hd_trainer* t) {
     if (!t) return;
     for (void* p : t->owned) (void)hipFree(p);
+    t->wg.destroy();
     delete t;
 }
 
@@ -590,22 +682,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->wt_tmp = (float*)need(dev_alloc<float>(t, wn));
     t->tail_flip = (float*)need(dev_alloc<float>(t, (size_t)9 * F));
     t->zero_bias = (float*)need(dev_alloc<float>(t, F, true));
-    // weight-gradient operand geometry
-    t->P = S + 8;
-    const size_t K = ((size_t)B * (S + 1) + 1) * t->P;
-    // 8 tiles of 128 x 64 (x 3 taps) per split; 64 splits = 512 workgroups = one round at two per CU, 8 splits per XCD
-    const size_t max_split = getenv("HICDIFF_WG_SPLITK") ? (size_t)atoi(getenv("HICDIFF_WG_SPLITK")) : 64;
-    t->splitK = (int)std::max<size_t>(1, std::min<size_t>(max_split, K / 2048));
-    if (t->splitK >= 8) t->splitK &= ~7;
-    t->Kpad = (K + (size_t)64 * t->splitK - 1) / ((size_t)64 * t->splitK) * ((size_t)64 * t->splitK);
-    t->kchunk = t->Kpad / t->splitK;
-    t->guard = ((size_t)t->P + 8 + 63) / 64 * 64;
-    t->ld = t->guard + t->Kpad + t->guard;
-    t->a_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
-    t->a_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
-    t->b_hi = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
-    t->b_lo = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)F * t->ld, true));
-    t->partial = (float*)need(dev_alloc<float>(t, (size_t)t->splitK * 3 * F * 3 * F));
+    if (!t->wg.init(B, S, S, F, F)) ok = false;
     t->colpart = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
     t->ctmp = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
     const size_t act = (size_t)B * S * S * F, pix = (size_t)B * S * S;
@@ -663,36 +740,12 @@ static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, in
 }
 
 static int prep(hd_trainer* tr, const float* in, bool gside, int mode, const float* film, float* colpart, hipStream_t st) {
-    const int F = tr->F, S = tr->S;
-    hd_prof_begin("wg_prep_kernel", 0.0, (double)tr->B * S * S * F * (4.0 + (tr->plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
-    if (tr->plain)
-        hipLaunchKernelGGL(wg_prep_kernel<true>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
-                           gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
-    else
-        hipLaunchKernelGGL(wg_prep_kernel<false>, dim3(tr->B * S), dim3(256), 0, st, in, F, S, S, tr->P, tr->ld, tr->guard, gside ? tr->b_hi : tr->a_hi,
-                           gside ? tr->b_lo : tr->a_lo, mode, film, tr->FW, colpart);
-    conv_prof_end(st);
-    return check_launch("wg_prep");
+    return tr->wg.rewrite(in, tr->F, 0, gside, mode, film, tr->FW, nullptr, colpart, tr->plain != 0, st);
 }
 
-// dW (+)= scale * wgrad(activation side already in a_*, gradient side already in b_*)
+// dW (+)= scale * wgrad(activation side already in the A image, gradient side already in the G image)
 static int wgrad(hd_trainer* tr, float scale, bool accumulate, float* dW, hipStream_t st) {
-    const int F = tr->F, Mt = F / 128;
-    static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
-    // algorithmic figures: 9 taps x F x F outputs over the B*S*S real pixels (3 MFMA flops per product are the kernel's business);
-    // bytes: both operand images once (hi + lo) + the partials
-    hd_prof_begin(tr->plain ? "wgrad_gemm_kernel<true>" : "wgrad_gemm_kernel<false>", 2.0 * 9 * F * F * (double)tr->B * tr->S * tr->S, (tr->plain ? 1.0 : 2.0) * 2 * 2 * F * (double)tr->Kpad + 4.0 * tr->splitK * 9 * F * F, st);
-    if (tr->plain)
-        hipLaunchKernelGGL(wgrad_gemm_kernel<true>, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
-                           tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
-    else
-        hipLaunchKernelGGL(wgrad_gemm_kernel<false>, dim3(Mt * (F / 64) * tr->splitK), dim3(256), 0, st, tr->a_hi, tr->a_lo, tr->b_hi, tr->b_lo, tr->ld, tr->guard,
-                           tr->P, tr->kchunk, tr->splitK, Mt, F / 64, F, F, tr->partial, xcd_group);
-    conv_prof_end(st);
-    if (check_launch("wgrad gemm")) return -3;
-    const size_t per = (size_t)3 * F * 3 * F;
-    hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, tr->partial, tr->splitK, F, scale, accumulate ? 1 : 0, dW);
-    return check_launch("wg_reduce");
+    return tr->wg.run(tr->F, tr->F, 3, scale, accumulate, dW, tr->plain != 0, st);
 }
 
 // db (+)= scale * column sums of the [B*S][F] row partials the last G-side prep wrote (two short serial stages)
@@ -837,4 +890,21 @@ extern "C" int hd_adam_step(float* params, const float* grads, float* m, float* 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (size_t)n, b1, b2, eps,
                        (float)(lr / c1), (float)(1.0 / std::sqrt(c2)), grad_scale);
     return check_launch("adam") == 0 ? HD_OK : HD_EHIP;
+}
+
+// ---- test-only entry (include/hicdiff_hip_debug.h): the weight-gradient component on arbitrary shapes ---------------------------
+extern "C" int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT, const float* affA,
+                                   const float* affB, int plain, float* dW, void* stream) {
+    if (!x0 || !g || !dW || B < 1 || H < 1 || W < 1 || W > 64 || C0 % 4 || C1 % 4 || (C1 && !x1) || Cout % 64 || (KT != 1 && KT != 3)) return HD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Wgrad wg;
+    const int Cin = C0 + C1;
+    if (!wg.init(B, H, W, Cin, Cout)) { wg.destroy(); return HD_ENOMEM; }
+    int rc = wg.rewrite(x0, C0, 0, false, affA ? 2 : 0, affA, Cin, affB, nullptr, plain != 0, st);
+    if (!rc && C1) rc = wg.rewrite(x1, C1, C0, false, affA ? 2 : 0, affA ? affA + C0 : nullptr, Cin, affA ? affB + C0 : nullptr, nullptr, plain != 0, st);
+    if (!rc) rc = wg.rewrite(g, Cout, 0, true, 0, nullptr, 0, nullptr, nullptr, plain != 0, st);
+    if (!rc) rc = wg.run(Cin, Cout, KT, 1.f, false, dW, plain != 0, st);
+    (void)hipStreamSynchronize(st);
+    wg.destroy();
+    return rc ? HD_EHIP : HD_OK;
 }

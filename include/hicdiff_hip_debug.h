@@ -33,6 +33,14 @@ int hd_debug_linattn_out(const float* q, const float* ctx, const float* wout, co
 int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, const float* ctx, const float* wout, const float* bias,
                        const float* gout, int B, int H, int W, float* out, void* stream);
 
+/* The weight-gradient component of the training step (csrc/train.hip, struct Wgrad) on an arbitrary shape:
+ * dW[Cout][C0+C1][KT][KT] = d/dW of conv2d(cat(x0, x1), W, padding = KT/2) contracted with g -- torch.nn.grad.conv2d_weight.
+ * x0: NHWC [B,H,W,C0]; x1: NHWC [B,H,W,C1] or NULL; g: NHWC [B,H,W,Cout]; KT = 3 or 1; W <= 64; Cout % 64 == 0.
+ * affA / affB ([B][C0+C1], may be NULL): the input is silu(x * affA + affB) per (sample, channel) -- a normalised activation
+ * recomputed on the way in.  plain != 0: one bf16 product instead of three.  Allocates and frees its operand images; synchronises. */
+int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT,
+                        const float* affA, const float* affB, int plain, float* dW, void* stream);
+
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.

@@ -311,3 +311,38 @@ def test_train_plain_bf16_option():
         ol, og = OTR.loss_and_grads(sd, cfg, buf, x0, t, eps, lq, "l2")
         OTR.adam_step(sd, og, om, ov, step, lr=2e-4)
         assert abs(float(loss.detach()) - float(ol)) <= 3e-2 * float(ol), step
+
+
+@pytest.mark.parametrize("B,S,C0,C1,Cout,KT,aff,plain", [
+    (2, 10, 64, 0, 64, 3, False, 0),       # 64 input channels: the activation image is padded to 128 rows
+    (3, 5, 128, 64, 128, 3, True, 0),      # channel concat + normalised-activation input, 5x5 map (row pitch 16)
+    (2, 20, 128, 64, 64, 1, False, 0),     # 1x1 filter (res_conv of an up block)
+    (1, 64, 64, 0, 64, 3, True, 0),
+    (2, 40, 256, 0, 256, 3, False, 1),     # plain bf16 products
+    (2, 8, 512, 512, 512, 3, False, 0),    # the widest UNet layer
+])
+def test_weight_gradient_component_any_shape(B, S, C0, C1, Cout, KT, aff, plain):
+    """The weight-gradient component (operand rewrite + GEMM + reduce) that the hicedrn trainer uses at 256 x 256 channels, on
+    the shapes the UNet's layers have, against torch's conv2d weight gradient (CPU fp32).  Groundwork for the UNet training step."""
+    import ctypes as C
+    from hicdiff_amd import _lib as L
+    lib = L.load()
+    lib.hd_debug_conv_wgrad.restype = C.c_int
+    lib.hd_debug_conv_wgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    gen = torch.Generator().manual_seed(B * 1000 + S)
+    Cin = C0 + C1
+    x = torch.randn((B, Cin, S, S), generator=gen)
+    g = torch.randn((B, Cout, S, S), generator=gen) * 0.1
+    A = torch.rand((B, Cin), generator=gen) + 0.5 if aff else None
+    Bv = torch.randn((B, Cin), generator=gen) * 0.3 if aff else None
+    xin = torch.nn.functional.silu(x * A[:, :, None, None] + Bv[:, :, None, None]) if aff else x
+    ref = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, KT, KT), g, padding=KT // 2)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    x0, x1 = nhwc(x[:, :C0]), (nhwc(x[:, C0:]) if C1 else None)
+    gd, out = nhwc(g), torch.empty((Cout, Cin, KT, KT), device="cuda")
+    ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+    Ad, Bd = (A.cuda().contiguous(), Bv.cuda().contiguous()) if aff else (None, None)
+    rc = lib.hd_debug_conv_wgrad(ptr(x0), C0, ptr(x1), C1, ptr(gd), B, S, S, Cout, KT, ptr(Ad), ptr(Bd), plain, ptr(out),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert rel_err(ref, out) <= (2e-2 if plain else 1e-4)

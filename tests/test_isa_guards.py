@@ -58,14 +58,15 @@ def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
     (4.6x slower).  The GEMM's slice loop must have no scratch traffic and must issue its 13 loads of a slice back to back."""
     text = _asm("train.hip")
     kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S))
-    # two instantiations: <false> = split-bf16 x3 (72 MFMAs and 13 loads per slice), <true> = plain bf16 (24 MFMAs, 7 loads)
-    for tag, mfmas, loads in (("ILb0E", 72, 13), ("ILb1E", 24, 7)):
+    # <PLAIN, ONE>: <false, false> = split-bf16 x3, three column taps (72 MFMAs and 13 loads per slice); <true, false> = plain bf16
+    # (24 MFMAs, 7 loads); <false, true> = 1x1 filter, split-bf16 x3 (24 MFMAs, 13 loads)
+    for tag, mfmas, loads in (("ILb0ELb0E", 72, 13), ("ILb1ELb0E", 24, 7), ("ILb0ELb1E", 24, 13)):
         name = next(k for k in kernels if "wgrad_gemm_kernel" in k and tag in k)
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
         # the slice loop is the innermost loop: no scratch traffic inside it (a few address registers may spill around the outer
         # row-shift loop, which runs three times)
-        inner = body[body.rindex("Depth=2"):]
+        inner = body[body.rindex("Depth=2" if "Depth=2" in body else "Depth=1"):]      # (the 1x1 variant has no row-shift loop around it)
         inner = inner[:inner.index("s_cbranch")]
         assert "scratch_" not in inner and inner.count("v_mfma") == mfmas, (tag, inner.count("v_mfma"))
         ops = [l.split()[0] for l in body.splitlines() if l.strip() and not l.strip().startswith((";", ".")) and not l.strip().endswith(":")]
