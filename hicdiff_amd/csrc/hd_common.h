@@ -109,7 +109,7 @@ int launch_film(const float* act, int Bt, int K, const float* wt, const float* b
 int launch_gn_partial(const float* x, int B, int HW, int C, float* part, int* slots_out, hipStream_t st);
 int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma,
                        const float* beta, const float* film, int film_bstride, int film_off, int film_mode,
-                       float* A, float* Bv, float* E, hipStream_t st);
+                       float* A, float* Bv, float* E, hipStream_t st, float* stats_out = nullptr);   // stats_out: [B][groups][2] (mean, rstd), training only
 int launch_affine_silu_add(const float* h, const float* A, const float* Bv, const float* res, float* out, int B, int HW, int C,
                            hipStream_t st, float* stats = nullptr);   // stats: see small_kernels.hip; returns 1 when it wrote them
 int launch_ln_stats(const float* x, size_t P, int C, float* stats, hipStream_t st);
@@ -131,6 +131,13 @@ int launch_split_pieces(const float* mat, int n, const int* origins, int ntiles,
 int launch_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, int step, float* mat, int n, hipStream_t st);
 int launch_tile_metrics(const float* pred, const float* target, int B, int S, int rescale, double* partial, double* sums, float* ssim_each,
                         hipStream_t st);
+// training components (train_norms.hip)
+size_t gn_bwd_scratch_floats(int B, int HW, int C);
+int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta, const float* film,
+                       int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta, float* dfilm,
+                       int accumulate, hipStream_t st);
+int launch_ln_bwd(const float* x, float* dy, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
+int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st);
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
                                                          int groups, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ film,
                                                          int film_bstride, int film_off, int film_mode,
-                                                         float* __restrict__ A, float* __restrict__ Bv, float* __restrict__ E) {
+                                                         float* __restrict__ A, float* __restrict__ Bv, float* __restrict__ E,
+                                                         float* __restrict__ stats_out) {
     // one wave per (sample, group): lanes stride over the group's slots x channels partial sums (fixed
     // order, so the result does not depend on anything but the tiling), fp64 combine.
     const int b = blockIdx.x / groups, g = blockIdx.x % groups, lane = threadIdx.x;
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     double var = s2 / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    if (stats_out && lane == 0) { stats_out[2 * blockIdx.x] = (float)mean; stats_out[2 * blockIdx.x + 1] = rstd; }   // training keeps (mean, rstd) per (sample, group)
     for (int j = lane; j < cg; j += 64) {
         const int c = g * cg + j, i = b * C + c;
         float a = rstd * gamma[c];
@@ -250,9 +252,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
 
 int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma, const float* beta,
                        const float* film, int film_bstride, int film_off, int film_mode, float* A, float* Bv, float* E,
-                       hipStream_t st) {
+                       hipStream_t st, float* stats_out) {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, st, part, slots, B, HW, C, groups, gamma,
-                       beta, film, film_bstride, film_off, film_mode, A, Bv, E);
+                       beta, film, film_bstride, film_off, film_mode, A, Bv, E, stats_out);
     return check_launch("gn_finalize");
 }
 

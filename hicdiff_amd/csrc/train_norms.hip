@@ -1,0 +1,260 @@
+// Backward passes of the UNet's normalisations -- components for its training step, each checked
+// against torch autograd through a test-only entry of include/hicdiff_hip_debug.h.  All reductions run in a fixed order.
+//
+//   GroupNorm(groups) -> [x (scale+1) + shift] -> SiLU      src/hicdiff.py:155-171 (Block.forward)
+//   channel LayerNorm (gain only, biased variance)           src/hicdiff.py:99-108
+//   weight standardisation of a conv filter                  src/hicdiff.py:84-97
+#include "hd_common.h"
+#include "../../include/hicdiff_hip.h"
+
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.f + v * (1.f - s)); }
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { hd_set_error(std::string(what) + ": " + hipGetErrorString(e)); return -3; }
+    return 0;
+}
+
+// ---- GroupNorm + FiLM + SiLU -------------------------------------------------------------------------------------------
+// x: raw conv output [B][HW][C]; g: dL/d(silu output); A, Bv: the forward's per-(sample, channel) affine (v = x A + Bv);
+// stats: [B][G][2] (mean, rstd).  part[(b*nchunk + ck)][2][C]: T1 = sum dv, T2 = sum dv * xhat over the chunk's pixels.
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ A,
+                                                             const float* __restrict__ Bv, const float* __restrict__ stats, int HW, int C, int G,
+                                                             int chunk, float* __restrict__ part) {
+    const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x, cg = C / G;
+    const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float a = A[(size_t)b * C + c], bb = Bv[(size_t)b * C + c];
+        const float mu = stats[((size_t)b * G + c / cg) * 2], rs = stats[((size_t)b * G + c / cg) * 2 + 1];
+        float t1 = 0.f, t2 = 0.f;
+        for (int p = p0; p < p1; ++p) {
+            const size_t e = ((size_t)b * HW + p) * C + c;
+            const float xv = x[e];
+            const float dv = g[e] * dsilu_f(xv * a + bb);
+            t1 += dv; t2 += dv * (xv - mu) * rs;
+        }
+        float* d = part + (size_t)(b * nchunk + ck) * 2 * C;
+        d[c] = t1; d[C + c] = t2;
+    }
+}
+
+// One workgroup per sample.  T: [B][2][C] (chunks already summed).  film: [B][film_bs] with scale at film_off + c and shift at
+// film_off + C + c (film_mode 1), or nothing (0).  Writes coef[b][c] = {rstd w, rstd M1_g, rstd M2_g, -} for the apply pass,
+// dfilm[b][2C] = (d scale, d shift) and U[b][2][C] = ((1+s) T2, (1+s) T1) whose sums over b are d gamma, d beta.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ T, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ film, int film_bs, int film_off,
+                                                              int film_mode, int HW, int C, int G, float4* __restrict__ coef, float* __restrict__ dfilm,
+                                                              float* __restrict__ U) {
+    __shared__ float m1[64], m2[64];
+    const int b = blockIdx.x, cg = C / G;
+    if (threadIdx.x < G) {                                   // one thread per group walks its channels in order
+        const int g0 = threadIdx.x * cg;
+        float s1 = 0.f, s2 = 0.f;
+        for (int j = 0; j < cg; ++j) {
+            const int c = g0 + j;
+            const float w = gamma[c] * (film_mode == 1 ? film[(size_t)b * film_bs + film_off + c] + 1.f : 1.f);
+            s1 += w * T[((size_t)b * 2) * C + c]; s2 += w * T[((size_t)b * 2 + 1) * C + c];
+        }
+        const float n = (float)HW * cg;
+        m1[threadIdx.x] = s1 / n; m2[threadIdx.x] = s2 / n;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int gi = c / cg;
+        const float rs = stats[((size_t)b * G + gi) * 2 + 1];
+        const float sc1 = film_mode == 1 ? film[(size_t)b * film_bs + film_off + c] + 1.f : 1.f;
+        const float t1 = T[((size_t)b * 2) * C + c], t2 = T[((size_t)b * 2 + 1) * C + c];
+        coef[(size_t)b * C + c] = make_float4(rs * gamma[c] * sc1, rs * m1[gi], rs * m2[gi], 0.f);
+        if (dfilm && film_mode == 1) { dfilm[(size_t)b * 2 * C + c] = gamma[c] * t2 + beta[c] * t1; dfilm[(size_t)b * 2 * C + C + c] = t1; }
+        U[((size_t)b * 2) * C + c] = sc1 * t2; U[((size_t)b * 2 + 1) * C + c] = sc1 * t1;
+    }
+}
+
+// g <- dL/dx = rstd (dv w - M1 - xhat M2), in place
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, float* __restrict__ g, const float* __restrict__ A,
+                                                           const float* __restrict__ Bv, const float* __restrict__ stats, const float4* __restrict__ coef,
+                                                           int HW, int C, int G, size_t n) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int c = (int)(e % C), b = (int)(e / ((size_t)HW * C)), cg = C / G;
+    const float xv = x[e];
+    const float dv = g[e] * dsilu_f(xv * A[(size_t)b * C + c] + Bv[(size_t)b * C + c]);
+    const float mu = stats[((size_t)b * G + c / cg) * 2], rs = stats[((size_t)b * G + c / cg) * 2 + 1];
+    const float4 k = coef[(size_t)b * C + c];
+    g[e] = dv * k.x - k.y - (xv - mu) * rs * k.z;
+}
+
+// out[col] (+)= sum_row in[row][col], eight independent chains; grid.y batches (in and out advance by nrows*ncols and ncols)
+__global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ in, int nrows, int ncols, int accumulate, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncols) return;
+    in += (size_t)blockIdx.y * nrows * ncols; out += (size_t)blockIdx.y * ncols;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 8 <= nrows; r += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += in[(size_t)(r + j) * ncols + col];
+    }
+    for (; r < nrows; ++r) a[r & 7] += in[(size_t)r * ncols + col];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    out[col] = (accumulate ? out[col] : 0.f) + s;
+}
+
+// ---- channel LayerNorm (gain only) ---------------------------------------------------------------------------------------
+// y = (x - mean_c) rstd g.  One wave per pixel row: dx = rstd (dy g - mean_c(dy g) - xhat mean_c(dy g xhat)), in place over dy;
+// part[blockIdx][C]: this workgroup's sum over its rows of dy * xhat (d gain), reduced afterwards.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, float* __restrict__ dy, const float* __restrict__ gain, size_t P, int C,
+                                                     int rows_per_block, float* __restrict__ part) {
+    extern __shared__ float dg[];                           // [4 waves][C]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float* mine = dg + (size_t)w * C;
+    for (int c = lane; c < C; c += 64) mine[c] = 0.f;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    for (int rr = w; rr < rows_per_block; rr += 4) {
+        const size_t r = r0 + rr;
+        if (r >= P) break;
+        const float* xr = x + r * C;
+        float* dr = dy + r * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float mean = s / C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+        const float rs = 1.f / sqrtf(q / C + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mean) * rs, d = dr[c] * gain[c];
+            s1 += d; s2 += d * xh;
+            mine[c] += dr[c] * xh;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        s1 /= C; s2 /= C;
+        for (int c = lane; c < C; c += 64) dr[c] = rs * (dr[c] * gain[c] - s1 - (xr[c] - mean) * rs * s2);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = (dg[c] + dg[C + c]) + (dg[2 * C + c] + dg[3 * C + c]);
+}
+
+// ---- weight standardisation ------------------------------------------------------------------------------------------------
+// What = (W - mean) rsqrt(var + 1e-5) per output filter (biased variance over its n = Cin*KH*KW entries);
+// dW = rstd (dWhat - mean(dWhat) - What mean(dWhat What)).  One workgroup per filter; fp64 sums as in pack_conv_kernel.
+__global__ __launch_bounds__(256) void ws_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dwhat, int n, float* __restrict__ dw) {
+    __shared__ double red[256];
+    const float* s = w + (size_t)blockIdx.x * n;
+    const float* d = dwhat + (size_t)blockIdx.x * n;
+    auto total = [&](double v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) { if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m]; __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
+    const double mean = total(acc) / n;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double t = s[i] - mean; acc += t * t; }
+    const double rstd = 1.0 / sqrt(total(acc) / n + 1e-5);
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double wh = (s[i] - mean) * rstd; a1 += d[i]; a2 += d[i] * wh; }
+    const double m1 = total(a1) / n, m2 = total(a2) / n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double wh = (s[i] - mean) * rstd;
+        dw[(size_t)blockIdx.x * n + i] = (float)(rstd * (d[i] - m1 - wh * m2));
+    }
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------
+// scratch: B * nchunk * 2C (partials) + B * 2C (T) + B * 2C (U) + B * C * 4 (coef) floats, nchunk = ceil(HW / 64)
+size_t gn_bwd_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + 63) / 64) * 2 * C + (size_t)B * 2 * C * 2 + (size_t)B * C * 4; }
+
+int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta, const float* film,
+                       int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta, float* dfilm,
+                       int accumulate, hipStream_t st) {
+    if (C % G || G > 64 || (film_mode != 0 && film_mode != 1)) { hd_set_error("gn backward: unsupported shape"); return -1; }
+    const int nchunk = (HW + 63) / 64;
+    float* part = scratch;
+    float* T = part + (size_t)B * nchunk * 2 * C;
+    float* U = T + (size_t)B * 2 * C;
+    float4* coef = reinterpret_cast<float4*>(U + (size_t)B * 2 * C);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, g, A, Bv, stats, HW, C, G, 64, part);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, st, part, nchunk, 2 * C, 0, T);      // T[b] = sum over the sample's chunks
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, T, stats, gamma, beta, film, film_bs, film_off, film_mode, HW, C, G, coef, dfilm, U);
+    const size_t n = (size_t)B * HW * C;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, g, A, Bv, stats, coef, HW, C, G, n);
+    // d gamma = sum_b U[b][0], d beta = sum_b U[b][1]: U viewed as [B rows][2C cols]
+    float* two = T;                                          // T is free again: [2C] = (d gamma | d beta)
+    hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, U, B, 2 * C, 0, two);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, two, 1, C, accumulate, dgamma);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, two + C, 1, C, accumulate, dbeta);
+    return check_launch("gn backward");
+}
+
+int launch_ln_bwd(const float* x, float* dy, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st) {
+    const int rows = 64;
+    const unsigned nb = (unsigned)((P + rows - 1) / rows);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, gain, P, C, rows, scratch);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, (int)nb, C, accumulate, dgain);
+    return check_launch("ln backward");
+}
+
+int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st) {
+    hipLaunchKernelGGL(ws_bwd_kernel, dim3(Cout), dim3(256), 0, st, w, dwhat, n, dw);
+    return check_launch("ws backward");
+}
+
+// ---- test-only entries (include/hicdiff_hip_debug.h) ------------------------------------------------------------------------
+extern "C" {
+
+int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const float* beta, const float* film, int B, int H, int W, int C, int G,
+                         float* dgamma, float* dbeta, float* dfilm, void* stream) {
+    if (!x || !g || !gamma || !beta || !dgamma || !dbeta || B < 1 || C % G) return HD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    int slots = 0;
+    float *part = nullptr, *A = nullptr, *Bv = nullptr, *stats = nullptr, *scratch = nullptr;
+    const size_t pslots = (size_t)(HW + 255) / 256;
+    bool ok = hipMalloc(&part, (size_t)B * pslots * C * 2 * sizeof(float)) == hipSuccess && hipMalloc(&A, (size_t)B * C * sizeof(float)) == hipSuccess &&
+              hipMalloc(&Bv, (size_t)B * C * sizeof(float)) == hipSuccess && hipMalloc(&stats, (size_t)B * G * 2 * sizeof(float)) == hipSuccess &&
+              hipMalloc(&scratch, gn_bwd_scratch_floats(B, HW, C) * sizeof(float)) == hipSuccess;
+    int rc = ok ? 0 : -4;
+    if (!rc) rc = launch_gn_partial(x, B, HW, C, part, &slots, st);
+    if (!rc) rc = launch_gn_finalize(part, slots, B, HW, C, G, gamma, beta, film, 2 * C, 0, film ? 1 : 0, A, Bv, nullptr, st, stats);
+    if (!rc) rc = launch_gn_silu_bwd(x, g, A, Bv, stats, gamma, beta, film, 2 * C, 0, film ? 1 : 0, B, HW, C, G, scratch, dgamma, dbeta, dfilm, 0, st);
+    (void)hipStreamSynchronize(st);
+    for (float* p : {part, A, Bv, stats, scratch}) if (p) (void)hipFree(p);
+    return rc ? (rc == -4 ? HD_ENOMEM : HD_EHIP) : HD_OK;
+}
+
+int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, int C, float* dgain, void* stream) {
+    if (!x || !dy || !gain || !dgain || P < 1 || C < 1) return HD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, ((size_t)(P + 63) / 64) * C * sizeof(float)) != hipSuccess) return HD_ENOMEM;
+    const int rc = launch_ln_bwd(x, dy, gain, (size_t)P, C, scratch, dgain, 0, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    return rc ? HD_EHIP : HD_OK;
+}
+
+int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, void* stream) {
+    if (!w || !dwhat || !dw || Cout < 1 || n < 1) return HD_EINVAL;
+    const int rc = launch_ws_bwd(w, dwhat, Cout, n, dw, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return rc ? HD_EHIP : HD_OK;
+}
+
+}  // extern "C"

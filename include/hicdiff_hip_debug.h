@@ -41,6 +41,17 @@ int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, c
 int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT,
                         const float* affA, const float* affB, int plain, float* dW, void* stream);
 
+/* Backward components of the UNet's normalisations (csrc/train_norms.hip; groundwork for its training step), against torch autograd:
+ *   hd_debug_gn_silu_bwd  y = silu(GroupNorm_G(x) * (scale + 1) + shift) (src/hicdiff.py:155-171): x NHWC [B,H,W,C]; g holds dL/dy on entry and
+ *                         dL/dx on return; film = [B][2C] (scale | shift) or NULL (no FiLM); dgamma, dbeta [C]; dfilm [B][2C] (may be NULL).
+ *   hd_debug_ln_bwd       y = (x - mean_c) rsqrt(var_c + 1e-5) * gain per pixel row (src/hicdiff.py:99-108): dy -> dx in place, dgain [C].
+ *   hd_debug_ws_bwd       dW from d(standardised W) per output filter (src/hicdiff.py:84-97); n = Cin*KH*KW.
+ * They allocate their scratch, run on the stream and synchronise. */
+int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const float* beta, const float* film, int B, int H, int W, int C, int G,
+                         float* dgamma, float* dbeta, float* dfilm, void* stream);
+int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, int C, float* dgain, void* stream);
+int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, void* stream);
+
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.

@@ -346,3 +346,76 @@ def test_weight_gradient_component_any_shape(B, S, C0, C1, Cout, KT, aff, plain)
                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     assert rel_err(ref, out) <= (2e-2 if plain else 1e-4)
+
+
+def _dbg(name, argtypes):
+    import ctypes as C
+    from hicdiff_amd import _lib as L
+    fn = getattr(L.load(), name)
+    fn.restype, fn.argtypes = C.c_int, argtypes
+    return fn
+
+
+@pytest.mark.parametrize("B,S,Cc,film", [(3, 8, 64, True), (2, 20, 128, True), (2, 5, 512, False), (1, 64, 64, True)])
+def test_groupnorm_film_silu_backward_component(B, S, Cc, film):
+    """d/dx, d/dgamma, d/dbeta, d/d(scale, shift) of silu(GroupNorm8(x) * (scale + 1) + shift) against torch autograd."""
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_gn_silu_bwd", [P] * 5 + [C.c_int] * 5 + [P] * 4)
+    gen = torch.Generator().manual_seed(Cc + S)
+    x = (torch.randn((B, Cc, S, S), generator=gen) * 1.5 + 0.3).requires_grad_(True)
+    gam = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    bet = (torch.randn(Cc, generator=gen) * 0.2).requires_grad_(True)
+    fs = (torch.randn((B, 2 * Cc), generator=gen) * 0.3).requires_grad_(True) if film else None
+    dy = torch.randn((B, Cc, S, S), generator=gen)
+    h = torch.nn.functional.group_norm(x, 8, gam, bet, eps=1e-5)
+    if film:
+        h = h * (fs[:, :Cc, None, None] + 1) + fs[:, Cc:, None, None]
+    torch.nn.functional.silu(h).backward(dy)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    xd, gd = nhwc(x), nhwc(dy)
+    dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    df = torch.empty((B, 2 * Cc), device="cuda") if film else None
+    ptr = lambda t: P(t.data_ptr()) if t is not None else P()
+    fsd = fs.detach().cuda().contiguous() if film else None
+    gamd, betd = gam.detach().cuda(), bet.detach().cuda()          # (kept alive: a temporary's block would be reused by the next one)
+    rc = fn(ptr(xd), ptr(gd), ptr(gamd), ptr(betd), ptr(fsd), B, S, S, Cc, 8, ptr(dg), ptr(db), ptr(df),
+            P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert rel_err(x.grad.permute(0, 2, 3, 1), gd) <= 1e-4
+    assert rel_err(gam.grad, dg) <= 1e-4 and rel_err(bet.grad, db) <= 1e-4
+    if film:
+        assert rel_err(fs.grad, df) <= 1e-4
+
+
+@pytest.mark.parametrize("P_,Cc", [(200, 64), (1000, 128), (75, 512)])
+def test_channel_layernorm_backward_component(P_, Cc):
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_ln_bwd", [P, P, P, C.c_longlong, C.c_int, P, P])
+    gen = torch.Generator().manual_seed(P_)
+    x = (torch.randn((P_, Cc), generator=gen) * 2 + 0.5).requires_grad_(True)
+    gain = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    dy = torch.randn((P_, Cc), generator=gen)
+    mean = x.mean(dim=1, keepdim=True)
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    ((x - mean) * (var + 1e-5).rsqrt() * gain).backward(dy)
+    xd, dyd, dgain, gaind = x.detach().cuda(), dy.cuda().clone(), torch.empty(Cc, device="cuda"), gain.detach().cuda()
+    rc = fn(P(xd.data_ptr()), P(dyd.data_ptr()), P(gaind.data_ptr()), P_, Cc, P(dgain.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and rel_err(x.grad, dyd) <= 1e-4 and rel_err(gain.grad, dgain) <= 1e-4
+
+
+@pytest.mark.parametrize("Cout,Cin,k", [(64, 64, 3), (128, 192, 3), (512, 1024, 3)])
+def test_weight_standardisation_backward_component(Cout, Cin, k):
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_ws_bwd", [P, P, C.c_int, C.c_int, P, P])
+    gen = torch.Generator().manual_seed(Cout + Cin)
+    w = (torch.randn((Cout, Cin, k, k), generator=gen) * 0.05).requires_grad_(True)
+    dwh = torch.randn((Cout, Cin, k, k), generator=gen)
+    mean = w.mean(dim=(1, 2, 3), keepdim=True)
+    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    ((w - mean) * (var + 1e-5).rsqrt()).backward(dwh)                       # src/hicdiff.py:89-97
+    wd, dd, out = w.detach().cuda(), dwh.cuda(), torch.empty_like(dwh, device="cuda")
+    rc = fn(P(wd.data_ptr()), P(dd.data_ptr()), Cout, Cin * k * k, P(out.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and rel_err(w.grad, out) <= 1e-5
