@@ -52,6 +52,10 @@ int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const flo
 int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, int C, float* dgain, void* stream);
 int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, void* stream);
 
+/* Backward of the attention cores (csrc/train_attn.hip), against torch autograd.  qkv: NHWC [B][n][3*heads*32] (q | k | v); dout: [B][n][heads*32];
+ * dqkv like qkv.  hd_debug_attn_full_bwd: softmax attention of the mid block (src/hicdiff.py:239-251), n <= 64 tokens. */
+int hd_debug_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
+
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.

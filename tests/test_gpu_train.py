@@ -419,3 +419,22 @@ def test_weight_standardisation_backward_component(Cout, Cin, k):
     wd, dd, out = w.detach().cuda(), dwh.cuda(), torch.empty_like(dwh, device="cuda")
     rc = fn(P(wd.data_ptr()), P(dd.data_ptr()), Cout, Cin * k * k, P(out.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
     assert rc == 0 and rel_err(w.grad, out) <= 1e-5
+
+
+@pytest.mark.parametrize("B,n", [(3, 64), (2, 25)])
+def test_full_attention_backward_component(B, n):
+    """d(q, k, v) of the mid block's softmax attention (src/hicdiff.py:239-251) against torch autograd."""
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_attn_full_bwd", [P, P, C.c_int, C.c_int, C.c_int, P, P])
+    heads, D = 4, 32
+    gen = torch.Generator().manual_seed(n)
+    qkv = torch.randn((B, n, 3 * heads * D), generator=gen).requires_grad_(True)
+    dout = torch.randn((B, n, heads * D), generator=gen)
+    q, k, v = (t.reshape(B, n, heads, D).permute(0, 2, 1, 3) for t in qkv.chunk(3, dim=2))        # b h n d
+    sim = torch.einsum("bhid,bhjd->bhij", q * D ** -0.5, k)
+    out = torch.einsum("bhij,bhjd->bhid", sim.softmax(dim=-1), v).permute(0, 2, 1, 3).reshape(B, n, heads * D)
+    out.backward(dout)
+    qd, dd, res = qkv.detach().cuda(), dout.cuda(), torch.empty((B, n, 3 * heads * D), device="cuda")
+    rc = fn(P(qd.data_ptr()), P(dd.data_ptr()), B, n, heads, P(res.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0 and rel_err(qkv.grad, res) <= 1e-4
