@@ -69,12 +69,180 @@ __global__ __launch_bounds__(256) void attn_full_bwd_kernel(const float* __restr
     }
 }
 
+
+// ---- LinearAttention ---------------------------------------------------------------------------------------------------------
+// Per (sample, head): q' = softmax_d(q) * scale per token; k' = softmax over tokens per d; v' = v / n;
+// context[d][e] = sum_n k'[d][n] v'[e][n];  out[e][n] = sum_d context[d][e] q'[d][n].
+// Backward in three passes over 64-token chunks (one wave per chunk, one token per lane):
+//   1. per chunk: m_c[d], s_c[d] (online-softmax pieces of k), ctx_c[d][e] = sum_n exp(k - m_c) v', dctx_c[d][e] = sum_n q' dout
+//   2. per (sample, head): combine -> M, S, context, dcontext, r[d] = sum_e dcontext[d][e] context[d][e]
+//      (= sum_n k'[d][n] dk'[d][n]: the softmax-over-tokens correction needs no further sweep)
+//   3. per chunk: dq, dk, dv of every token.
+// part layout per (sample, head, chunk): [m 32][s 32][ctx 1024][dctx 1024]; fin per (sample, head): [M 32][S 32][r 32][context 1024][dcontext 1024].
+constexpr int LA_PART = 64 + 2048, LA_FIN = 96 + 2048, LA_TOK = 64;
+
+__device__ __forceinline__ void la_load_row(const float* p, float (&r)[D]) {
+#pragma unroll
+    for (int j = 0; j < D; j += 4) { const float4 t = *reinterpret_cast<const float4*>(p + j); r[j] = t.x; r[j + 1] = t.y; r[j + 2] = t.z; r[j + 3] = t.w; }
+}
+__device__ __forceinline__ void la_softmax_d(float (&q)[D]) {
+    float mx = q[0];
+#pragma unroll
+    for (int j = 1; j < D; ++j) mx = fmaxf(mx, q[j]);
+    float den = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) { q[j] = __expf(q[j] - mx); den += q[j]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int j = 0; j < D; ++j) q[j] *= inv;
+}
+
+__global__ __launch_bounds__(64) void linattn_bwd_partial_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, int n, int heads, int nchunk,
+                                                                 float* __restrict__ part) {
+    __shared__ float kk[LA_TOK][D + 1], vv[LA_TOK][D + 1], qq[LA_TOK][D + 1], dd[LA_TOK][D + 1], mm[D];
+    const int ck = blockIdx.x % nchunk, bh = blockIdx.x / nchunk, b = bh / heads, h = bh % heads, lane = threadIdx.x;
+    const int C3 = 3 * heads * D, C1 = heads * D, tok = ck * LA_TOK + lane;
+    const bool on = tok < n;
+    float q[D], k[D], v[D], g[D];
+    if (on) {
+        const float* row = qkv + ((size_t)b * n + tok) * C3 + h * D;
+        la_load_row(row, q); la_load_row(row + C1, k); la_load_row(row + 2 * C1, v);
+        la_load_row(dout + ((size_t)b * n + tok) * C1 + h * D, g);
+        la_softmax_d(q);
+    }
+    const float invn = 1.f / (float)n;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        kk[lane][j] = on ? k[j] : -3.0e38f; vv[lane][j] = on ? v[j] * invn : 0.f;
+        qq[lane][j] = on ? q[j] * SCALE : 0.f; dd[lane][j] = on ? g[j] : 0.f;
+    }
+    __syncthreads();
+    float* out = part + (size_t)blockIdx.x * LA_PART;
+    if (lane < D) {                                          // lane = d: max and sum of exp over the chunk's tokens
+        float mx = -3.0e38f;
+        for (int t = 0; t < LA_TOK; ++t) mx = fmaxf(mx, kk[t][lane]);
+        float s = 0.f;
+        for (int t = 0; t < LA_TOK; ++t) { const float e = kk[t][lane] > -1.0e38f ? __expf(kk[t][lane] - mx) : 0.f; kk[t][lane] = e; s += e; }
+        mm[lane] = mx; out[lane] = mx; out[D + lane] = s;
+    }
+    __syncthreads();
+    for (int i = lane; i < D * D; i += 64) {                // (d, e) pairs
+        const int d = i / D, e = i % D;
+        float c = 0.f, dc = 0.f;
+        for (int t = 0; t < LA_TOK; ++t) { c += kk[t][d] * vv[t][e]; dc += qq[t][d] * dd[t][e]; }
+        out[64 + i] = c; out[64 + 1024 + i] = dc;
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_bwd_combine_kernel(const float* __restrict__ part, int nchunk, float* __restrict__ fin) {
+    __shared__ float M[D], S[D], red[256];
+    const float* p = part + (size_t)blockIdx.x * nchunk * LA_PART;
+    float* out = fin + (size_t)blockIdx.x * LA_FIN;
+    const int tid = threadIdx.x;
+    if (tid < D) {
+        float mx = -3.0e38f;
+        for (int c = 0; c < nchunk; ++c) mx = fmaxf(mx, p[(size_t)c * LA_PART + tid]);
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += p[(size_t)c * LA_PART + D + tid] * __expf(p[(size_t)c * LA_PART + tid] - mx);
+        M[tid] = mx; S[tid] = s; out[tid] = mx; out[D + tid] = s;
+    }
+    __syncthreads();
+    float rpart[4];
+    for (int j = 0; j < 4; ++j) {                            // element i = tid + 256 j = (d, e); d = i / 32 is the same for 32 consecutive i
+        const int i = tid + 256 * j, d = i / D;
+        float c = 0.f, dc = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const float* q = p + (size_t)ch * LA_PART;
+            c += q[64 + i] * __expf(q[d] - M[d]);
+            dc += q[64 + 1024 + i];
+        }
+        c /= S[d];
+        out[96 + i] = c; out[96 + 1024 + i] = dc;
+        rpart[j] = c * dc;
+    }
+    // r[d] = sum_e context[d][e] dcontext[d][e]: 32 consecutive threads of each j hold one d
+    for (int j = 0; j < 4; ++j) {
+        red[tid] = rpart[j];
+        __syncthreads();
+        if ((tid & 31) == 0) { float s = 0.f; for (int e = 0; e < D; ++e) s += red[tid + e]; out[2 * D + (tid + 256 * j) / D] = s; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void linattn_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ fin, int n,
+                                                               int heads, int nchunk, float* __restrict__ dqkv) {
+    __shared__ float ctx[D][D + 1], dctx[D][D + 1], M[D], S[D], R[D];
+    const int ck = blockIdx.x % nchunk, bh = blockIdx.x / nchunk, b = bh / heads, h = bh % heads, lane = threadIdx.x;
+    const float* f = fin + (size_t)bh * LA_FIN;
+    for (int i = lane; i < D * D; i += 64) { ctx[i / D][i % D] = f[96 + i]; dctx[i / D][i % D] = f[96 + 1024 + i]; }
+    if (lane < D) { M[lane] = f[lane]; S[lane] = f[D + lane]; R[lane] = f[2 * D + lane]; }
+    __syncthreads();
+    const int C3 = 3 * heads * D, C1 = heads * D, tok = ck * LA_TOK + lane;
+    if (tok >= n) return;
+    const float* row = qkv + ((size_t)b * n + tok) * C3 + h * D;
+    float q[D], k[D], v[D], g[D];
+    la_load_row(row, q); la_load_row(row + C1, k); la_load_row(row + 2 * C1, v);
+    la_load_row(dout + ((size_t)b * n + tok) * C1 + h * D, g);
+    la_softmax_d(q);
+    const float invn = 1.f / (float)n;
+    float t[D], dot = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {                            // d q'[d] = sum_e context[d][e] dout[e]; times scale
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; ++e) s += ctx[d][e] * g[e];
+        t[d] = s * SCALE; dot += q[d] * t[d];
+    }
+    float* drow = dqkv + ((size_t)b * n + tok) * C3 + h * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+        *reinterpret_cast<float4*>(drow + d) = make_float4(q[d] * (t[d] - dot), q[d + 1] * (t[d + 1] - dot), q[d + 2] * (t[d + 2] - dot), q[d + 3] * (t[d + 3] - dot));
+    float kp[D], dv[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) dv[e] = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        kp[d] = __expf(k[d] - M[d]) / S[d];
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < D; ++e) { s += dctx[d][e] * v[e]; dv[e] += kp[d] * dctx[d][e]; }
+        k[d] = kp[d] * (s * invn - R[d]);                    // d k[d]
+    }
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+        *reinterpret_cast<float4*>(drow + C1 + d) = make_float4(k[d], k[d + 1], k[d + 2], k[d + 3]);
+        *reinterpret_cast<float4*>(drow + 2 * C1 + d) = make_float4(dv[d] * invn, dv[d + 1] * invn, dv[d + 2] * invn, dv[d + 3] * invn);
+    }
+}
+
 }  // namespace
 
 int launch_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, hipStream_t st) {
     if (n < 1 || n > 64) { hd_set_error("full-attention backward: at most 64 tokens"); return -1; }
     hipLaunchKernelGGL(attn_full_bwd_kernel, dim3(B * heads), dim3(256), 0, st, qkv, dout, n, heads, dqkv);
     return check_launch("attn_full_bwd");
+}
+
+size_t linattn_bwd_scratch_floats(int B, int n, int heads) { return (size_t)B * heads * (((size_t)n + LA_TOK - 1) / LA_TOK * LA_PART + LA_FIN); }
+
+int launch_linattn_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* scratch, float* dqkv, hipStream_t st) {
+    const int nchunk = (n + LA_TOK - 1) / LA_TOK;
+    float* part = scratch;
+    float* fin = scratch + (size_t)B * heads * nchunk * LA_PART;
+    hipLaunchKernelGGL(linattn_bwd_partial_kernel, dim3(B * heads * nchunk), dim3(64), 0, st, qkv, dout, n, heads, nchunk, part);
+    hipLaunchKernelGGL(linattn_bwd_combine_kernel, dim3(B * heads), dim3(256), 0, st, part, nchunk, fin);
+    hipLaunchKernelGGL(linattn_bwd_apply_kernel, dim3(B * heads * nchunk), dim3(64), 0, st, qkv, dout, fin, n, heads, nchunk, dqkv);
+    return check_launch("linattn_bwd");
+}
+
+extern "C" int hd_debug_linattn_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream) {
+    if (!qkv || !dout || !dqkv || B < 1 || heads < 1 || n < 1) return HD_EINVAL;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, linattn_bwd_scratch_floats(B, n, heads) * sizeof(float)) != hipSuccess) return HD_ENOMEM;
+    const int rc = launch_linattn_bwd(qkv, dout, B, n, heads, scratch, dqkv, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(scratch);
+    return rc ? HD_EHIP : HD_OK;
 }
 
 extern "C" int hd_debug_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream) {

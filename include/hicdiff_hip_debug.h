@@ -55,6 +55,8 @@ int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* 
 /* Backward of the attention cores (csrc/train_attn.hip), against torch autograd.  qkv: NHWC [B][n][3*heads*32] (q | k | v); dout: [B][n][heads*32];
  * dqkv like qkv.  hd_debug_attn_full_bwd: softmax attention of the mid block (src/hicdiff.py:239-251), n <= 64 tokens. */
 int hd_debug_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
+/* hd_debug_linattn_bwd: the LinearAttention core (src/hicdiff.py:212-224: q softmax over d, k softmax over tokens, q * scale, v / n, context, out), any n. */
+int hd_debug_linattn_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
 
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);

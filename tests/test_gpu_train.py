@@ -438,3 +438,26 @@ def test_full_attention_backward_component(B, n):
     qd, dd, res = qkv.detach().cuda(), dout.cuda(), torch.empty((B, n, 3 * heads * D), device="cuda")
     rc = fn(P(qd.data_ptr()), P(dd.data_ptr()), B, n, heads, P(res.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
     assert rc == 0 and rel_err(qkv.grad, res) <= 1e-4
+
+
+@pytest.mark.parametrize("B,n", [(2, 100), (3, 256), (1, 1600), (2, 4096)])
+def test_linear_attention_backward_component(B, n):
+    """d(q, k, v) of the LinearAttention core (src/hicdiff.py:212-224) against torch autograd."""
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_linattn_bwd", [P, P, C.c_int, C.c_int, C.c_int, P, P])
+    heads, D = 4, 32
+    gen = torch.Generator().manual_seed(n + B)
+    qkv = (torch.randn((B, n, 3 * heads * D), generator=gen) * 1.5).requires_grad_(True)
+    dout = torch.randn((B, n, heads * D), generator=gen)
+    q, k, v = (t.reshape(B, n, heads, D).permute(0, 2, 3, 1) for t in qkv.chunk(3, dim=2))        # b h d n
+    q = q.softmax(dim=-2) * D ** -0.5
+    k = k.softmax(dim=-1)
+    ctx = torch.einsum("bhdn,bhen->bhde", k, v / n)
+    out = torch.einsum("bhde,bhdn->bhen", ctx, q).permute(0, 3, 1, 2).reshape(B, n, heads * D)
+    out.backward(dout)
+    qd, dd, res = qkv.detach().cuda(), dout.cuda(), torch.empty((B, n, 3 * heads * D), device="cuda")
+    rc = fn(P(qd.data_ptr()), P(dd.data_ptr()), B, n, heads, P(res.data_ptr()), P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    for name, sl in (("q", slice(0, 128)), ("k", slice(128, 256)), ("v", slice(256, 384))):
+        assert rel_err(qkv.grad[..., sl], res[..., sl]) <= 1e-4, name
