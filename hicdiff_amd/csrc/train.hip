@@ -42,7 +42,10 @@ template <bool PLAIN>      // PLAIN: hi image only (the optional bf16 arithmetic
 __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
                                                       const float* __restrict__ film, int film_bs, float* __restrict__ colpart, int row0,
-                                                      const float* __restrict__ affB) {
+                                                      const float* __restrict__ affB, int src_mode) {
+    // src_mode 0: `in` is [B][H][W][C].  1: nearest x2 upsample on the way in (Upsample, src/hicdiff.py:72-76): `in` is [B][H/2][W/2][C].
+    // 2: pixel-unshuffle on the way in (Downsample, src/hicdiff.py:78-82, 'b c (h p1) (w p2) -> b (c p1 p2) h w'): `in` is [B][2H][2W][C/4]
+    //    and logical channel cc = c*4 + p1*2 + p2 reads (2y + p1, 2x + p2, c).
     // mode 0: raw; mode 1: silu(v * (film[b][c] + 1) + film[b][film_bs - C + c]) (film_bs == C: no scale) -- the hicedrn block;
     // mode 2: silu(v * film[b*film_bs + c] + affB[b*film_bs + c]) -- a GroupNorm'd, FiLM'd activation given as a per-(sample, channel) affine.
     // grid.y walks the channels in chunks of 256; row0 = first image row this tensor's channels go to (channel-concatenated inputs).
@@ -66,10 +69,17 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
             shf = *reinterpret_cast<const float4*>(affB + (size_t)b * film_bs + cg);
         }
         const float* src = in + ((size_t)(b * H + y) * W) * C + cg;
+        if (src_mode == 1) src = in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2)) * C + cg;
+        const int Cs = C / 4, cs = cg >> 2;                    // unshuffle: source channels, this quad's source channel
         for (int x = pgp; x < W8; x += 4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // columns W .. W8-1 of the last 8-pixel group stay zero (they are padding)
             if (x < W) {
-                v = *reinterpret_cast<const float4*>(src + (size_t)x * C);
+                if (src_mode == 2) {
+                    const float* s0 = in + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * Cs + cs;
+                    v = make_float4(s0[0], s0[Cs], s0[(size_t)2 * W * Cs], s0[(size_t)2 * W * Cs + Cs]);   // (p1,p2) = (0,0), (0,1), (1,0), (1,1)
+                } else {
+                    v = *reinterpret_cast<const float4*>(src + (size_t)(src_mode == 1 ? x >> 1 : x) * C);
+                }
                 if (mode) { v.x = silu_f(v.x * sc.x + shf.x); v.y = silu_f(v.y * sc.y + shf.y); v.z = silu_f(v.z * sc.z + shf.z); v.w = silu_f(v.w * sc.w + shf.w); }
             }
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
@@ -532,15 +542,15 @@ struct Wgrad {
         return a_hi && a_lo && b_hi && b_lo && partial;
     }
     int rewrite(const float* in, int C, int row0, bool gside, int mode, const float* film, int film_bs, const float* affB, float* colpart, bool plain,
-                hipStream_t st) const {
+                hipStream_t st, int src_mode = 0) const {
         hd_prof_begin("wg_prep_kernel", 0.0, (double)B * H * W * C * (4.0 + (plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
         const dim3 grid(B * H, (C + 255) / 256);
         if (plain)
             hipLaunchKernelGGL(wg_prep_kernel<true>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
-                               film_bs, colpart, row0, affB);
+                               film_bs, colpart, row0, affB, src_mode);
         else
             hipLaunchKernelGGL(wg_prep_kernel<false>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
-                               film_bs, colpart, row0, affB);
+                               film_bs, colpart, row0, affB, src_mode);
         conv_prof_end(st);
         return check_launch("wg_prep");
     }
@@ -892,6 +902,49 @@ extern "C" int hd_adam_step(float* params, const float* grads, float* m, float* 
     return check_launch("adam") == 0 ? HD_OK : HD_EHIP;
 }
 
+// ---- gradient routing of the resampling layers -------------------------------------------------------------------------------------
+namespace {
+// Upsample backward: dx[b][y][x][c] = sum of the 2x2 block of the upsampled map's gradient.  g: [B][2H][2W][C], dx: [B][H][W][C].
+__global__ __launch_bounds__(256) void sum_pool2_kernel(const float* __restrict__ g, int H, int W, int C4, size_t n4, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4); size_t r = i / C4;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H), b = (int)(r / H);
+    const float4* p = reinterpret_cast<const float4*>(g) + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C4 + c;
+    const float4 a = p[0], bq = p[C4], cq = p[(size_t)2 * W * C4], d = p[(size_t)2 * W * C4 + C4];
+    reinterpret_cast<float4*>(dx)[i] = make_float4((a.x + bq.x) + (cq.x + d.x), (a.y + bq.y) + (cq.y + d.y), (a.z + bq.z) + (cq.z + d.z), (a.w + bq.w) + (cq.w + d.w));
+}
+// Downsample backward: dx[b][2y+p1][2x+p2][c] = g[b][y][x][c*4 + p1*2 + p2].  g: [B][H][W][4C], dx: [B][2H][2W][C].
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ g, int H, int W, int C, size_t n, float* __restrict__ dx) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over g's quads: (b, y, x, c)
+    if (i >= n) return;
+    const int c = (int)(i % C); size_t r = i / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H), b = (int)(r / H);
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    float* d = dx + (((size_t)b * 2 * H + 2 * y) * 2 * W + 2 * x) * C + c;
+    d[0] = v.x; d[C] = v.y; d[(size_t)2 * W * C] = v.z; d[(size_t)2 * W * C + C] = v.w;
+}
+}  // namespace
+
+int launch_sum_pool2(const float* g, int B, int H, int W, int C, float* dx, hipStream_t st) {
+    const size_t n4 = (size_t)B * H * W * C / 4;
+    hipLaunchKernelGGL(sum_pool2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, H, W, C / 4, n4, dx);
+    return check_launch("sum_pool2");
+}
+int launch_pixel_shuffle(const float* g, int B, int H, int W, int C, float* dx, hipStream_t st) {
+    const size_t n = (size_t)B * H * W * C;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, H, W, C, n, dx);
+    return check_launch("pixel_shuffle");
+}
+extern "C" int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C, int which, float* dx, void* stream) {
+    if (!g || !dx || B < 1 || C % 4) return HD_EINVAL;
+    const int rc = which == 1 ? launch_sum_pool2(g, B, H, W, C, dx, (hipStream_t)stream) : launch_pixel_shuffle(g, B, H, W, C, dx, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    return rc ? HD_EHIP : HD_OK;
+}
+
 // ---- test-only entry (include/hicdiff_hip_debug.h): the weight-gradient component on arbitrary shapes ---------------------------
 extern "C" int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT, const float* affA,
                                    const float* affB, int plain, float* dW, void* stream) {
@@ -900,7 +953,9 @@ extern "C" int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int
     Wgrad wg;
     const int Cin = C0 + C1;
     if (!wg.init(B, H, W, Cin, Cout)) { wg.destroy(); return HD_ENOMEM; }
-    int rc = wg.rewrite(x0, C0, 0, false, affA ? 2 : 0, affA, Cin, affB, nullptr, plain != 0, st);
+    const int src_mode = plain >> 1;                           // bits above bit 0 of `plain`: 1 = x0 is the half-size map to upsample, 2 = x0 is the double-size map to unshuffle
+    plain &= 1;
+    int rc = wg.rewrite(x0, C0, 0, false, affA ? 2 : 0, affA, Cin, affB, nullptr, plain != 0, st, src_mode);
     if (!rc && C1) rc = wg.rewrite(x1, C1, C0, false, affA ? 2 : 0, affA ? affA + C0 : nullptr, Cin, affA ? affB + C0 : nullptr, nullptr, plain != 0, st);
     if (!rc) rc = wg.rewrite(g, Cout, 0, true, 0, nullptr, 0, nullptr, nullptr, plain != 0, st);
     if (!rc) rc = wg.run(Cin, Cout, KT, 1.f, false, dW, plain != 0, st);

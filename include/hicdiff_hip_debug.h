@@ -37,7 +37,9 @@ int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, c
  * dW[Cout][C0+C1][KT][KT] = d/dW of conv2d(cat(x0, x1), W, padding = KT/2) contracted with g -- torch.nn.grad.conv2d_weight.
  * x0: NHWC [B,H,W,C0]; x1: NHWC [B,H,W,C1] or NULL; g: NHWC [B,H,W,Cout]; KT = 3 or 1; W <= 64; Cout % 64 == 0.
  * affA / affB ([B][C0+C1], may be NULL): the input is silu(x * affA + affB) per (sample, channel) -- a normalised activation
- * recomputed on the way in.  plain != 0: one bf16 product instead of three.  Allocates and frees its operand images; synchronises. */
+ * recomputed on the way in.  plain bit 0: one bf16 product instead of three; plain >> 1 = source addressing of x0: 1 = x0 is the half-size map
+ * [B,H/2,W/2,C0] taken through a nearest x2 upsample (Upsample, src/hicdiff.py:72-76), 2 = x0 is the double-size map [B,2H,2W,C0/4] taken through
+ * the pixel-unshuffle (Downsample, :78-82; channel c*4 + p1*2 + p2).  Allocates and frees its operand images; synchronises. */
 int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT,
                         const float* affA, const float* affB, int plain, float* dW, void* stream);
 
@@ -51,6 +53,10 @@ int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const flo
                          float* dgamma, float* dbeta, float* dfilm, void* stream);
 int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, int C, float* dgain, void* stream);
 int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, void* stream);
+
+/* Gradient routing of the resampling layers: which == 1: 2x2 sum-pool (g [B,2H,2W,C] -> dx [B,H,W,C]); which == 2: pixel-shuffle (g [B,H,W,4C] ->
+ * dx [B,2H,2W,C], g's channel c*4 + p1*2 + p2 goes to pixel (2y+p1, 2x+p2)).  C here is dx's channel count. */
+int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C, int which, float* dx, void* stream);
 
 /* Backward of the attention cores (csrc/train_attn.hip), against torch autograd.  qkv: NHWC [B][n][3*heads*32] (q | k | v); dout: [B][n][heads*32];
  * dqkv like qkv.  hd_debug_attn_full_bwd: softmax attention of the mid block (src/hicdiff.py:239-251), n <= 64 tokens. */

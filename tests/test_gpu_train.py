@@ -461,3 +461,43 @@ def test_linear_attention_backward_component(B, n):
     assert rc == 0
     for name, sl in (("q", slice(0, 128)), ("k", slice(128, 256)), ("v", slice(256, 384))):
         assert rel_err(qkv.grad[..., sl], res[..., sl]) <= 1e-4, name
+
+
+def test_resampling_layers_backward_components():
+    """Upsample (nearest x2 -> conv 3x3) and Downsample (pixel-unshuffle -> conv 1x1), src/hicdiff.py:72-82: the weight gradient with
+    the resampling done as source addressing of the operand rewrite, and the routing of the data gradient back through it."""
+    import ctypes as C
+    from einops import rearrange
+    P = C.c_void_p
+    wg = _dbg("hd_debug_conv_wgrad", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, C.c_int, P, P])
+    rs = _dbg("hd_debug_resample_bwd", [P] + [C.c_int] * 5 + [P, P])
+    st = P(torch.cuda.current_stream().cuda_stream)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    gen = torch.Generator().manual_seed(17)
+    B, Cc, Cout, H = 2, 128, 64, 20                      # the map after the layer is H x H
+    # Upsample: x is H/2 x H/2
+    x = torch.randn((B, Cc, H // 2, H // 2), generator=gen).requires_grad_(True)
+    g = torch.randn((B, Cout, H, H), generator=gen) * 0.1
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    ref = torch.nn.grad.conv2d_weight(up, (Cout, Cc, 3, 3), g, padding=1)
+    xd, gd, out = nhwc(x), nhwc(g), torch.empty((Cout, Cc, 3, 3), device="cuda")
+    assert wg(P(xd.data_ptr()), Cc, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 3, P(), P(), 2, P(out.data_ptr()), st) == 0
+    assert rel_err(ref, out) <= 1e-4
+    gup = torch.randn((B, Cc, H, H), generator=gen)
+    up.backward(gup)
+    gud, dx = nhwc(gup), torch.empty((B, H // 2, H // 2, Cc), device="cuda")
+    assert rs(P(gud.data_ptr()), B, H // 2, H // 2, Cc, 1, P(dx.data_ptr()), st) == 0
+    assert rel_err(x.grad.permute(0, 2, 3, 1), dx) <= 1e-6
+    # Downsample: x is 2H x 2H with Cs channels, the 1x1 conv sees 4 Cs channels at H x H
+    Cs = 64
+    x = torch.randn((B, Cs, 2 * H, 2 * H), generator=gen).requires_grad_(True)
+    un = rearrange(x, "b c (h p1) (w p2) -> b (c p1 p2) h w", p1=2, p2=2)
+    ref = torch.nn.grad.conv2d_weight(un, (Cout, 4 * Cs, 1, 1), g)
+    xd, out = nhwc(x), torch.empty((Cout, 4 * Cs, 1, 1), device="cuda")
+    assert wg(P(xd.data_ptr()), 4 * Cs, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 1, P(), P(), 4, P(out.data_ptr()), st) == 0
+    assert rel_err(ref, out) <= 1e-4
+    gun = torch.randn((B, 4 * Cs, H, H), generator=gen)
+    un.backward(gun)
+    gnd, dx = nhwc(gun), torch.empty((B, 2 * H, 2 * H, Cs), device="cuda")
+    assert rs(P(gnd.data_ptr()), B, H, H, Cs, 2, P(dx.data_ptr()), st) == 0
+    assert torch.equal(x.grad.permute(0, 2, 3, 1).contiguous(), dx.cpu())
