@@ -139,6 +139,8 @@ int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv
 int launch_ln_bwd(const float* x, float* dy, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
 int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st);
 int launch_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, hipStream_t st);   // train_attn.hip
+int launch_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* scratch, float* dW, hipStream_t st);
+int launch_rowdot_bwd(const float* x, const float* dout, const float* w, size_t P, int C, float* scratch, float* dx, float* dw, hipStream_t st);
 int launch_sum_pool2(const float* g, int B, int H, int W, int C, float* dx, hipStream_t st);        // train.hip: Upsample backward (g is [B][2H][2W][C])
 int launch_pixel_shuffle(const float* g, int B, int H, int W, int C, float* dx, hipStream_t st);    // Downsample backward (g is [B][H][W][4C])
 size_t linattn_bwd_scratch_floats(int B, int n, int heads);

@@ -419,37 +419,53 @@ __global__ __launch_bounds__(256) void sin_emb_kernel(const void* __restrict__ t
 }
 
 // ---- first / last convolution weight gradients (1-2 channels on one side) -----------------------------------------------
-// part[(b*nrb + rb)][c][j*9 + tap] = sum over the row block of big[p][c] * small_j[p + sign*(tap offset)]
+// part[(b*nrb + rb)][c][j*KS*KS + tap] = sum over the row block of big[p][c] * small_j[p + sign*(tap offset)]
+// KS = 3 (hicedrn head / tail) or 7 (the UNet's init_conv, src/hicdiff.py:279).
+template <int KS>
 __global__ __launch_bounds__(256) void small_conv_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ s0, const float* __restrict__ s1,
                                                                int J, int S, int C, int RB, int sign, float* __restrict__ part) {
-    extern __shared__ float sm[];                           // [J][RB+2][S+2]
-    const int b = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x, y0 = rb * RB, LW = S + 2, LH = RB + 2;
+    constexpr int R = KS / 2, T = KS * KS;
+    extern __shared__ float sm[];                           // [J][RB + 2R][S + 2R]
+    const int b = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x, y0 = rb * RB, LW = S + 2 * R, LH = RB + 2 * R;
     for (int i = threadIdx.x; i < J * LH * LW; i += 256) {
         const int j = i / (LH * LW), r = (i / LW) % LH, x = i % LW;
-        const int yy = y0 + r - 1, xx = x - 1;
+        const int yy = y0 + r - R, xx = x - R;
         const float* src = j == 0 ? s0 : s1;
         sm[i] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? src[((size_t)b * S + yy) * S + xx] : 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        float acc[2][9];
+        for (int j = 0; j < J; ++j) {                       // one small plane at a time: T accumulators per thread
+            float acc[T];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int t = 0; t < T; ++t) acc[t] = 0.f;
+            for (int yy = 0; yy < RB && y0 + yy < S; ++yy)
+                for (int x = 0; x < S; ++x) {
+                    const float v = big[(((size_t)b * S + y0 + yy) * S + x) * C + c];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) acc[j][t] = 0.f;
-        for (int yy = 0; yy < RB && y0 + yy < S; ++yy)
-            for (int x = 0; x < S; ++x) {
-                const float v = big[(((size_t)b * S + y0 + yy) * S + x) * C + c];
+                    for (int t = 0; t < T; ++t) acc[t] += v * sm[(j * LH + yy + R + sign * (t / KS - R)) * LW + x + R + sign * (t % KS - R)];
+                }
+            float* d = part + ((size_t)(b * nrb + rb) * C + c) * (J * T) + j * T;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    if (j < J)
-#pragma unroll
-                        for (int t = 0; t < 9; ++t)
-                            acc[j][t] += v * sm[(j * LH + yy + 1 + sign * (t / 3 - 1)) * LW + x + 1 + sign * (t % 3 - 1)];
-            }
-        float* d = part + ((size_t)(b * nrb + rb) * C + c) * (J * 9);
-        for (int j = 0; j < J; ++j)
-            for (int t = 0; t < 9; ++t) d[j * 9 + t] = acc[j][t];
+            for (int t = 0; t < T; ++t) d[t] = acc[t];
+        }
+    }
+}
+
+// ---- the UNet's 1x1 final convolution (C -> 1, src/hicdiff.py:319): out[p] = sum_c x[p][c] w[c] + b ----------------------------------
+// part[block][c] = sum over the block's pixels of x[p][c] * dout[p] (d w); dx[p][c] = dout[p] * w[c]
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, const float* __restrict__ w, size_t P, int C,
+                                                         int rows, float* __restrict__ dx, float* __restrict__ part) {
+    const size_t p0 = (size_t)blockIdx.x * rows;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float wc = w[c];
+        float s = 0.f;
+        for (int r = 0; r < rows && p0 + r < P; ++r) {
+            const float g = dout[p0 + r];
+            s += x[(p0 + r) * C + c] * g;
+            dx[(p0 + r) * C + c] = g * wc;
+        }
+        part[(size_t)blockIdx.x * C + c] = s;
     }
 }
 
@@ -829,7 +845,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     // ---- backward
     const int RB = 8, nrb = (S + RB - 1) / RB;
     // tail: dW[0][ci][tap] = sum_p Y[p + tap][ci] dout[p]; db = sum dout; dY = conv(dout, flipped tail weight)
-    hipLaunchKernelGGL(small_conv_wgrad_kernel, dim3(nrb, B), dim3(256), (size_t)(RB + 2) * (S + 2) * sizeof(float), st, tr->Y, tr->dout, (const float*)nullptr, 1, S, F, RB,
+    hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), (size_t)(RB + 2) * (S + 2) * sizeof(float), st, tr->Y, tr->dout, (const float*)nullptr, 1, S, F, RB,
                        -1, tr->spart);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9, 1.f, 0, grads + tr->o_tail_w);
     TR_TRY(check_launch("tail wgrad"));
@@ -869,7 +885,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     // head: d(head output) = dx + dY (the skip r); dW[co][cin][tap] = sum_p in_cin[p + tap] d[p][co]
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, dY, n4, da);
     const float* s0 = tr->cin0 == 2 ? cond : tr->xt;
-    hipLaunchKernelGGL(small_conv_wgrad_kernel, dim3(nrb, B), dim3(256), (size_t)tr->cin0 * (RB + 2) * (S + 2) * sizeof(float), st, da, s0, tr->xt, tr->cin0, S, F,
+    hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), (size_t)tr->cin0 * (RB + 2) * (S + 2) * sizeof(float), st, da, s0, tr->xt, tr->cin0, S, F,
                        RB, 1, tr->spart);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 * tr->cin0 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9 * tr->cin0, 1.f, 0, grads + tr->o_head_w);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F + 255) / 256, B * S), dim3(256), 0, st, da, S, F, 1.f, 0, tr->colpart);
@@ -900,6 +916,45 @@ extern "C" int hd_adam_step(float* params, const float* grads, float* m, float* 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, (size_t)n, b1, b2, eps,
                        (float)(lr / c1), (float)(1.0 / std::sqrt(c2)), grad_scale);
     return check_launch("adam") == 0 ? HD_OK : HD_EHIP;
+}
+
+// ---- first / last convolutions of the UNet as components ----------------------------------------------------------------------------------
+// dW[C][J][KS][KS] = sum_p in_j[p + tap] * g[p][c] (the first convolution: J = 1 or 2 single-channel input planes, g = gradient of its
+// C-channel output); scratch: B * ceil(S/8) * C * J*KS*KS floats
+int launch_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* scratch, float* dW, hipStream_t st) {
+    const int RB = 8, nrb = (S + RB - 1) / RB, R = KS / 2, T = KS * KS;
+    const size_t lds = (size_t)J * (RB + 2 * R) * (S + 2 * R) * sizeof(float);
+    if (KS == 7) hipLaunchKernelGGL(small_conv_wgrad_kernel<7>, dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    else if (KS == 3) hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    else { hd_set_error("first-conv weight gradient: 3x3 or 7x7"); return -1; }
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C * J * T + 255) / 256, 1), dim3(256), 0, st, scratch, B * nrb, C * J * T, 1.f, 0, dW);
+    return check_launch("first conv wgrad");
+}
+// final 1x1 convolution C -> 1: dx[p][c] = dout[p] w[c]; dw[c] = sum_p x[p][c] dout[p]; scratch: ceil(P/64) * C floats
+int launch_rowdot_bwd(const float* x, const float* dout, const float* w, size_t P, int C, float* scratch, float* dx, float* dw, hipStream_t st) {
+    const int rows = 64;
+    const unsigned nb = (unsigned)((P + rows - 1) / rows);
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(nb), dim3(256), 0, st, x, dout, w, P, C, rows, dx, scratch);
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, st, scratch, (int)nb, C, 1.f, 0, dw);
+    return check_launch("rowdot backward");
+}
+extern "C" int hd_debug_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* dW, void* stream) {
+    if (!g || !in0 || !dW || J < 1 || J > 2 || (J == 2 && !in1)) return HD_EINVAL;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)B * ((S + 7) / 8) * C * J * KS * KS * sizeof(float)) != hipSuccess) return HD_ENOMEM;
+    const int rc = launch_first_conv_wgrad(g, in0, in1, J, B, S, C, KS, scratch, dW, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(scratch);
+    return rc ? (rc == -1 ? HD_EINVAL : HD_EHIP) : HD_OK;
+}
+extern "C" int hd_debug_rowdot_bwd(const float* x, const float* dout, const float* w, long long P, int C, float* dx, float* dw, void* stream) {
+    if (!x || !dout || !w || !dx || !dw || P < 1) return HD_EINVAL;
+    float* scratch = nullptr;
+    if (hipMalloc(&scratch, ((size_t)(P + 63) / 64) * C * sizeof(float)) != hipSuccess) return HD_ENOMEM;
+    const int rc = launch_rowdot_bwd(x, dout, w, (size_t)P, C, scratch, dx, dw, (hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(scratch);
+    return rc ? HD_EHIP : HD_OK;
 }
 
 // ---- gradient routing of the resampling layers -------------------------------------------------------------------------------------

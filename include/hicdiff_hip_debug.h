@@ -54,6 +54,12 @@ int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const flo
 int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, int C, float* dgain, void* stream);
 int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, void* stream);
 
+/* First / last convolutions of the UNet: hd_debug_first_conv_wgrad: dW[C][J][KS][KS] of a KS x KS (3 or 7), same-padded convolution of J (1 or 2)
+ * single-channel planes in0, in1 ([B][S][S]) into C channels, given the gradient g ([B,S,S,C]) of its output (init_conv, src/hicdiff.py:279).
+ * hd_debug_rowdot_bwd: the 1x1 convolution C -> 1 (final_conv, :319): dx[p][c] = dout[p] w[c], dw[c] = sum_p x[p][c] dout[p]. */
+int hd_debug_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* dW, void* stream);
+int hd_debug_rowdot_bwd(const float* x, const float* dout, const float* w, long long P, int C, float* dx, float* dw, void* stream);
+
 /* Gradient routing of the resampling layers: which == 1: 2x2 sum-pool (g [B,2H,2W,C] -> dx [B,H,W,C]); which == 2: pixel-shuffle (g [B,H,W,4C] ->
  * dx [B,2H,2W,C], g's channel c*4 + p1*2 + p2 goes to pixel (2y+p1, 2x+p2)).  C here is dx's channel count. */
 int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C, int which, float* dx, void* stream);

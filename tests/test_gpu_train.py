@@ -501,3 +501,31 @@ def test_resampling_layers_backward_components():
     gnd, dx = nhwc(gun), torch.empty((B, 2 * H, 2 * H, Cs), device="cuda")
     assert rs(P(gnd.data_ptr()), B, H, H, Cs, 2, P(dx.data_ptr()), st) == 0
     assert torch.equal(x.grad.permute(0, 2, 3, 1).contiguous(), dx.cpu())
+
+
+def test_first_and_last_convolution_backward_components():
+    """init_conv (7x7, 1 or 2 single-channel inputs -> 64, src/hicdiff.py:279) weight gradient; final_conv (1x1, 64 -> 1, :319) both gradients."""
+    import ctypes as C
+    P = C.c_void_p
+    fc = _dbg("hd_debug_first_conv_wgrad", [P, P, P] + [C.c_int] * 5 + [P, P])
+    rd = _dbg("hd_debug_rowdot_bwd", [P, P, P, C.c_longlong, C.c_int, P, P, P])
+    st = P(torch.cuda.current_stream().cuda_stream)
+    gen = torch.Generator().manual_seed(23)
+    for J, S, KS in ((2, 40, 7), (1, 16, 7), (2, 24, 3)):
+        B, Cc = 3, 64
+        x = torch.randn((B, J, S, S), generator=gen)
+        g = torch.randn((B, Cc, S, S), generator=gen) * 0.1
+        ref = torch.nn.grad.conv2d_weight(x, (Cc, J, KS, KS), g, padding=KS // 2)
+        planes = [x[:, j].contiguous().cuda() for j in range(J)]
+        gd, out = g.permute(0, 2, 3, 1).contiguous().cuda(), torch.empty((Cc, J, KS, KS), device="cuda")
+        rc = fc(P(gd.data_ptr()), P(planes[0].data_ptr()), P(planes[1].data_ptr()) if J == 2 else P(), J, B, S, Cc, KS, P(out.data_ptr()), st)
+        assert rc == 0 and rel_err(ref, out) <= 1e-5, (J, S, KS)
+    Pn, Cc = 3 * 40 * 40, 64
+    x = torch.randn((Pn, Cc), generator=gen).requires_grad_(True)
+    w = torch.randn(Cc, generator=gen).requires_grad_(True)
+    dout = torch.randn(Pn, generator=gen)
+    (x @ w).backward(dout)
+    xd, dd, wd = x.detach().cuda(), dout.cuda(), w.detach().cuda()
+    dx, dw = torch.empty((Pn, Cc), device="cuda"), torch.empty(Cc, device="cuda")
+    assert rd(P(xd.data_ptr()), P(dd.data_ptr()), P(wd.data_ptr()), Pn, Cc, P(dx.data_ptr()), P(dw.data_ptr()), st) == 0
+    assert rel_err(x.grad, dx) <= 1e-6 and rel_err(w.grad, dw) <= 1e-5
