@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <deque>
 #include <string>
 #include <vector>
 
@@ -271,12 +272,12 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
     *d = (accumulate ? *d : 0.f) + scale * s;
 }
 
-// data-gradient weight: Wt[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]  (both torch layout)
-__global__ __launch_bounds__(256) void flip_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wt) {
+// data-gradient weight: Wt[ci][co][ky][kx] = W[co][ci][K-1-ky][K-1-kx]  (both torch layout; KK = K*K taps, 9 or 1)
+__global__ __launch_bounds__(256) void flip_weight_kernel(const float* __restrict__ w, int Cout, int Cin, float* __restrict__ wt, int KK = 9) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (size_t)Cout * Cin * 9) return;
-    const int tap = (int)(i % 9), co = (int)((i / 9) % Cout), ci = (int)(i / ((size_t)9 * Cout));
-    wt[i] = w[((size_t)co * Cin + ci) * 9 + (8 - tap)];
+    if (i >= (size_t)Cout * Cin * KK) return;
+    const int tap = (int)(i % KK), co = (int)((i / KK) % Cout), ci = (int)(i / ((size_t)KK * Cout));
+    wt[i] = w[((size_t)co * Cin + ci) * KK + (KK - 1 - tap)];
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------
@@ -596,8 +597,10 @@ struct Wgrad {
 };
 
 // =====================================================================================================================
+struct UnetTrainer;
 struct hd_trainer {
     hd_arch_desc arch{};
+    UnetTrainer* unet = nullptr;          // set for the UNet (train_unet.inc); the fields below the layout are then unused
     int device = 0, B = 0, S = 0, F = 256, nres = 0, cin0 = 1, tdim = 1024, FW = 512;   // FW: FiLM row width (2F; F for SR3's additive form)
     std::string err;
     struct Slot { std::string name; size_t off, n; int ndim; long long shape[4]; };
@@ -647,6 +650,8 @@ template <class T> static T* dev_alloc(hd_trainer* t, size_t n, bool zero = fals
     return (T*)p;
 }
 
+#include "train_unet.inc"
+
 extern "C" {
 
 const char* hd_train_last_error(const hd_trainer* t) { return t ? t->err.c_str() : t_err.c_str(); }
@@ -655,13 +660,26 @@ void hd_train_destroy(hd_trainer* t) {
     if (!t) return;
     for (void* p : t->owned) (void)hipFree(p);
     t->wg.destroy();
+    if (t->unet) { t->unet->destroy(); delete t->unet; }
     delete t;
 }
 
 int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, int S) {
     if (!out || !a) return HD_EINVAL;
     *out = nullptr;
-    if (a->kind != HD_ARCH_HICEDRN) return tfail(nullptr, HD_EINVAL, "native training covers the hicedrn networks (unconditional / self_condition / SR3); the UNet is not built yet");
+    if (a->kind == HD_ARCH_UNET) {
+        if (a->sr3) return tfail(nullptr, HD_EINVAL, "native training of the SR3 UNet is not built yet");
+        if (a->dim % 64 || a->n_mults < 1 || a->n_mults > 4 || B < 1 || S < 8 || S > 64 || (S >> (a->n_mults - 1)) < 4 || S % (1 << (a->n_mults - 1)))
+            return tfail(nullptr, HD_EINVAL, "UNet training: dim a multiple of 64, at most 4 levels, 8 <= S <= 64 divisible by 2^(levels-1)");
+        if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, HD_EHIP, "hipSetDevice failed");
+        hd_trainer* t = new hd_trainer();
+        t->arch = *a; t->device = device; t->B = B; t->S = S;
+        t->unet = new UnetTrainer();
+        if (!t->unet->init(t, B, S)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the UNet trainer"); }
+        *out = t;
+        return HD_OK;
+    }
+    if (a->kind != HD_ARCH_HICEDRN) return tfail(nullptr, HD_EINVAL, "unknown architecture");
     if (a->dim != 256 || a->number_resnet < 1) return tfail(nullptr, HD_EINVAL, "hicedrn: n_feat must be 256");
     if (B < 1 || S < 8 || S > 64 || S % 8) return tfail(nullptr, HD_EINVAL, "training tiles: 8 <= S <= 64, S a multiple of 8");
     if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, HD_EHIP, "hipSetDevice failed");
@@ -784,6 +802,13 @@ static int colsum(hd_trainer* tr, float scale, bool accumulate, float* db, hipSt
 extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float* grads, const float* x_start, const float* cond, const void* t, int t_kind,
                                       const float* noise, const float* a_t, const float* s_t, int l2, float* loss, void* stream) {
     if (!tr || !params || !grads || !x_start || !t || !noise || !a_t || !s_t || !loss) return HD_EINVAL;
+    if (tr->unet) {
+        if ((tr->arch.self_condition != 0) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
+        if (t_kind != HD_T_INT64) return tfail(tr, HD_EINVAL, "the UNet takes integer timesteps");
+        tr->err.clear();
+        const int rc = tr->unet->step(params, grads, x_start, cond, t, noise, a_t, s_t, l2, loss, (hipStream_t)stream);
+        return rc == 0 ? HD_OK : tfail(tr, rc == -4 ? HD_ENOMEM : HD_EHIP, "UNet training step failed (see hd_last_error)");
+    }
     if ((tr->cin0 == 2) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
     hipStream_t st = (hipStream_t)stream;
     const int F = tr->F, S = tr->S, B = tr->B, n = tr->nres, TD = tr->tdim, HW = S * S, FW = tr->FW;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ T, const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, const float* __restrict__ film, int film_bs, int film_off,
                                                               int film_mode, int HW, int C, int G, float4* __restrict__ coef, float* __restrict__ dfilm,
-                                                              float* __restrict__ U) {
+                                                              float* __restrict__ U, int dfilm_bs) {
     __shared__ float m1[64], m2[64];
     const int b = blockIdx.x, cg = C / G;
     if (threadIdx.x < G) {                                   // one thread per group walks its channels in order
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
         const float sc1 = film_mode == 1 ? film[(size_t)b * film_bs + film_off + c] + 1.f : 1.f;
         const float t1 = T[((size_t)b * 2) * C + c], t2 = T[((size_t)b * 2 + 1) * C + c];
         coef[(size_t)b * C + c] = make_float4(rs * gamma[c] * sc1, rs * m1[gi], rs * m2[gi], 0.f);
-        if (dfilm && film_mode == 1) { dfilm[(size_t)b * 2 * C + c] = gamma[c] * t2 + beta[c] * t1; dfilm[(size_t)b * 2 * C + C + c] = t1; }
+        if (dfilm && film_mode == 1) { dfilm[(size_t)b * dfilm_bs + c] = gamma[c] * t2 + beta[c] * t1; dfilm[(size_t)b * dfilm_bs + C + c] = t1; }
         U[((size_t)b * 2) * C + c] = sc1 * t2; U[((size_t)b * 2 + 1) * C + c] = sc1 * t1;
     }
 }
@@ -175,7 +175,33 @@ __global__ __launch_bounds__(256) void ws_bwd_kernel(const float* __restrict__ w
     }
 }
 
+// What (torch layout) of a filter bank, the same arithmetic as pack_conv_kernel's standardize
+__global__ __launch_bounds__(256) void ws_fwd_kernel(const float* __restrict__ w, int n, float* __restrict__ out) {
+    __shared__ double red[256];
+    const float* s = w + (size_t)blockIdx.x * n;
+    auto total = [&](double v) {
+        red[threadIdx.x] = v;
+        __syncthreads();
+        for (int m = 128; m > 0; m >>= 1) { if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m]; __syncthreads(); }
+        const double r = red[0];
+        __syncthreads();
+        return r;
+    };
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += s[i];
+    const double mean = total(acc) / n;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double t = s[i] - mean; acc += t * t; }
+    const double rstd = 1.0 / sqrt(total(acc) / n + 1e-5);
+    for (int i = threadIdx.x; i < n; i += 256) out[(size_t)blockIdx.x * n + i] = (float)((s[i] - mean) * rstd);
+}
+
 }  // namespace
+
+int launch_ws_fwd(const float* w, int Cout, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(ws_fwd_kernel, dim3(Cout), dim3(256), 0, st, w, n, out);
+    return check_launch("ws forward");
+}
 
 // ---- launchers ---------------------------------------------------------------------------------------------------------
 // scratch: B * nchunk * 2C (partials) + B * 2C (T) + B * 2C (U) + B * C * 4 (coef) floats, nchunk = ceil(HW / 64)
@@ -183,7 +209,8 @@ size_t gn_bwd_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + 6
 
 int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta, const float* film,
                        int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta, float* dfilm,
-                       int accumulate, hipStream_t st) {
+                       int accumulate, hipStream_t st, int dfilm_bs) {
+    if (dfilm_bs <= 0) dfilm_bs = 2 * C;                       // dfilm rows: (d scale | d shift) at dfilm + b * dfilm_bs
     if (C % G || G > 64 || (film_mode != 0 && film_mode != 1)) { hd_set_error("gn backward: unsupported shape"); return -1; }
     const int nchunk = (HW + 63) / 64;
     float* part = scratch;
@@ -192,7 +219,7 @@ int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv
     float4* coef = reinterpret_cast<float4*>(U + (size_t)B * 2 * C);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, g, A, Bv, stats, HW, C, G, 64, part);
     hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, st, part, nchunk, 2 * C, 0, T);      // T[b] = sum over the sample's chunks
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, T, stats, gamma, beta, film, film_bs, film_off, film_mode, HW, C, G, coef, dfilm, U);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, T, stats, gamma, beta, film, film_bs, film_off, film_mode, HW, C, G, coef, dfilm, U, dfilm_bs);
     const size_t n = (size_t)B * HW * C;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, g, A, Bv, stats, coef, HW, C, G, n);
     // d gamma = sum_b U[b][0], d beta = sum_b U[b][1]: U viewed as [B rows][2C cols]
@@ -233,7 +260,7 @@ int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const flo
     int rc = ok ? 0 : -4;
     if (!rc) rc = launch_gn_partial(x, B, HW, C, part, &slots, st);
     if (!rc) rc = launch_gn_finalize(part, slots, B, HW, C, G, gamma, beta, film, 2 * C, 0, film ? 1 : 0, A, Bv, nullptr, st, stats);
-    if (!rc) rc = launch_gn_silu_bwd(x, g, A, Bv, stats, gamma, beta, film, 2 * C, 0, film ? 1 : 0, B, HW, C, G, scratch, dgamma, dbeta, dfilm, 0, st);
+    if (!rc) rc = launch_gn_silu_bwd(x, g, A, Bv, stats, gamma, beta, film, 2 * C, 0, film ? 1 : 0, B, HW, C, G, scratch, dgamma, dbeta, dfilm, 0, st, 0);
     (void)hipStreamSynchronize(st);
     for (float* p : {part, A, Bv, stats, scratch}) if (p) (void)hipFree(p);
     return rc ? (rc == -4 ? HD_ENOMEM : HD_EHIP) : HD_OK;

@@ -529,3 +529,34 @@ def test_first_and_last_convolution_backward_components():
     dx, dw = torch.empty((Pn, Cc), device="cuda"), torch.empty(Cc, device="cuda")
     assert rd(P(xd.data_ptr()), P(dd.data_ptr()), P(wd.data_ptr()), Pn, Cc, P(dx.data_ptr()), P(dw.data_ptr()), st) == 0
     assert rel_err(x.grad, dx) <= 1e-6 and rel_err(w.grad, dw) <= 1e-5
+
+
+def _unet_diffusion(kind, dim, mults, S, loss="l2"):
+    from _util import product_unet
+    m = product_unet(kind, dim=dim, mults=mults)
+    if kind == "cond":
+        from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+    else:
+        from hicdiff_amd.hicdiff import GaussianDiffusion
+    return GaussianDiffusion(m, image_size=S, timesteps=1000, loss_type=loss, beta_schedule="linear").cuda()
+
+
+@pytest.mark.parametrize("kind,dim,mults,B,S", [("cond", 64, (1, 2), 2, 16), ("uncond", 64, (1, 2, 4), 2, 32)])
+def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
+    """The UNet's native training step: every entry of every gradient against torch autograd over the oracle net (CPU fp32)."""
+    from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
+    d = _unet_diffusion(kind, dim, mults, S)
+    d.train()
+    cfg = ON.UnetCfg(dim=dim, dim_mults=tuple(mults), self_condition=(kind != "uncond"), sr3=False)
+    sd = W.fill_state_dict(W.unet_shapes(dim=dim, dim_mults=tuple(mults), self_condition=cfg.self_condition, sr3=False))
+    x0, lq = tiles(51, B, S), tiles(52, B, S)
+    gen = torch.Generator().manual_seed(7)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen), torch.randn(x0.shape, generator=gen)
+    ol, og = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("linear", 1000), x0, t, eps, None if kind == "uncond" else lq, "l2")
+    val = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
+    assert val.requires_grad
+    val.backward()
+    assert abs(float(val.detach()) - float(ol)) <= 1e-4 * float(ol)
+    errs = {k: rel_err(og[k], p.grad) for k, p in d.model.named_parameters()}
+    bad = {k: v for k, v in errs.items() if not v <= 1e-3}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
