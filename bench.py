@@ -135,8 +135,12 @@ def bench_train(args):
     from hicdiff_amd.optim import Adam
     batch, tile, blocks = args.batch or 64, args.tile or 64, args.blocks
     torch.manual_seed(1234)
-    d = GaussianDiffusion(hicedrn_Diff(number_resnet=blocks, self_condition=True), image_size=tile, timesteps=1000, loss_type="l2",
-                          beta_schedule="linear").to(dev)
+    if args.train_arch == "unet":
+        from hicdiff_amd.hicdiff_condition import Unet
+        net = Unet(64, dim_mults=(1, 2, 4, 8), self_condition=True)
+    else:
+        net = hicedrn_Diff(number_resnet=blocks, self_condition=True)
+    d = GaussianDiffusion(net, image_size=tile, timesteps=1000, loss_type="l2", beta_schedule="linear").to(dev)
     d.model.train_precision = args.train_precision
     d.train()
     opt = Adam(d.parameters(), lr=2e-5)
@@ -195,6 +199,8 @@ def bench_train(args):
     if rank == 0:
         ms = dt / args.steps * 1e3
         flop_tile = 2 * 9 * 256 * 256 * tile * tile * (2 * blocks + 1) * 3        # forward + data gradient + weight gradient of the 256->256 convs
+        if args.train_arch == "unet":
+            flop_tile = 3 * 14.384e9 * (tile / 64.0) ** 2                        # 3 x the forward's algorithmic flops
         achieved = flop_tile * batch / (ms / 1e3) / 1e12
         kernels = {}
         for name, r in prof.items():
@@ -204,11 +210,12 @@ def bench_train(args):
         dom = max(kernels, key=lambda k: kernels[k]["launches"] * kernels[k]["avg_launch_us"]) if kernels else None
         per_product = 3 if args.train_precision == "bf16x3" else 1
         print(json.dumps({
-            "metric": "training tiles/sec (hicedrn, l2, Adam)", "value": round(batch * world / (ms / 1e3), 2), "unit": "tiles/s", "n_gpus": world,
+            "metric": f"training tiles/sec ({args.train_arch}, l2, Adam)", "value": round(batch * world / (ms / 1e3), 2), "unit": "tiles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 master weights and gradients; products " + ("split-bf16 x3 MFMA" if args.train_precision == "bf16x3" else "bf16 MFMA (one per product)") + ", fp32 accumulate",
             "data": "synthetic",
-            "config": {"workload": f"hicedrn64_train: hicedrn x{blocks} blocks, conditional, {batch} tiles of 1x{tile}x{tile} per GPU, Adam lr 2e-5",
+            "config": {"workload": (f"hicedrn64_train: hicedrn x{blocks} blocks" if args.train_arch == "hicedrn" else "hicedrn64_train --train-arch unet: UNet(64, (1,2,4,8))") +
+                                   f", conditional, {batch} tiles of 1x{tile}x{tile} per GPU, Adam lr 2e-5",
                        "tiles_per_gpu": batch, "tile": tile, "parallelism": f"data-parallel x{world}, one flat-gradient all-reduce per step"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPs"] if dom else None, "peak": round(PEAK_BF16_MFMA_TFLOPS / per_product, 1),
                          "unit": "TFLOP/s", "frac": round(kernels[dom]["TFLOPs"] / (PEAK_BF16_MFMA_TFLOPS / per_product), 4) if dom else None, "traffic": None,
@@ -291,6 +298,7 @@ def main():
     ap.add_argument("--workload", default="unet64", choices=sorted(WORK) + ["hicedrn64_train", "tiles"])
     ap.add_argument("--tile", type=int, default=None, help="hicedrn64_train / tiles: tile size (default 64)")
     ap.add_argument("--blocks", type=int, default=32, help="hicedrn64_train: residual blocks")
+    ap.add_argument("--train-arch", choices=["hicedrn", "unet"], default="hicedrn", help="hicedrn64_train: which eps-network to train")
     ap.add_argument("--train-precision", choices=["bf16x3", "bf16"], default="bf16x3", help="hicedrn64_train: products of the convolutions (bf16: one MFMA per product)")
     ap.add_argument("--matrix-size", type=int, default=24896, help="tiles: matrix side (chr1 at 10 kb)")
     ap.add_argument("--res", type=int, default=10000, help="tiles: bin size")

@@ -101,7 +101,7 @@ class NativeTrainer:
             rc = self.lib.hd_train_loss_backward(self.h, _ptr(self.flat), _ptr(self.grads), _ptr(x_start), _ptr(cond), _ptr(t), kind, _ptr(noise),
                                                  _ptr(a_t), _ptr(s_t), 1 if l2 else 0, _ptr(self.loss), st)
         if rc != 0:
-            raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
+            raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode() + " / " + (self.lib.hd_last_error(None) or b"").decode())
         self.serial = getattr(self, "serial", 0) + 1
         return _NativeLoss.apply(self.anchor, self, self.loss.clone(), self.serial)
 

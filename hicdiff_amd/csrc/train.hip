@@ -658,6 +658,7 @@ const char* hd_train_last_error(const hd_trainer* t) { return t ? t->err.c_str()
 
 void hd_train_destroy(hd_trainer* t) {
     if (!t) return;
+    (void)hipDeviceSynchronize();         // nothing of this trainer may still be running when its buffers go
     for (void* p : t->owned) (void)hipFree(p);
     t->wg.destroy();
     if (t->unet) { t->unet->destroy(); delete t->unet; }
@@ -807,7 +808,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         if (t_kind != HD_T_INT64) return tfail(tr, HD_EINVAL, "the UNet takes integer timesteps");
         tr->err.clear();
         const int rc = tr->unet->step(params, grads, x_start, cond, t, noise, a_t, s_t, l2, loss, (hipStream_t)stream);
-        return rc == 0 ? HD_OK : tfail(tr, rc == -4 ? HD_ENOMEM : HD_EHIP, "UNet training step failed (see hd_last_error)");
+        return rc == 0 ? HD_OK : tfail(tr, rc == -4 ? HD_ENOMEM : HD_EHIP, "UNet training step: " + (tr->unet->why.empty() ? std::string("a launch failed") : tr->unet->why));
     }
     if ((tr->cin0 == 2) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
     hipStream_t st = (hipStream_t)stream;

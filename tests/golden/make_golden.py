@@ -497,7 +497,53 @@ def case_train():
     save("train", **out)
 
 
+def case_train_unet():
+    """pretrain/train_unet_*.py's step (the same four lines as train.py:131-134) on a two-level UNet (dim 64, dim_mults (1, 2): both
+    attention kinds, both resampling kinds, a concatenating up path): loss.backward() + Adam for two steps, conditional and unconditional."""
+    from oracle import train as OTR
+    out = {}
+    B, S, T = 2, 16, 1000
+    x0, lq = tiles(23, B, S), tiles(24, B, S)
+    for kind in ("cond", "uncond"):
+        m, cfg = build_unet(kind, dim=64, mults=(1, 2))
+        m.train()
+        d = (R1 if kind == "cond" else R0).GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        names = [k for k, _ in m.named_parameters()]
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        buf = OD.diffusion_buffers("linear", T)
+        opt = torch.optim.Adam(d.parameters(), lr=2e-5)
+        om, ov = {k: torch.zeros_like(sd[k]) for k in names}, {k: torch.zeros_like(sd[k]) for k in names}
+        op = {k: sd[k].clone() for k in names}
+        with torch.enable_grad():
+            for step in (1, 2):
+                torch.manual_seed(400 + step)
+                loss = d(x0 if kind == "uncond" else [lq, x0])
+                loss.backward()
+                torch.manual_seed(400 + step)
+                t = torch.randint(0, T, (B,)).long()
+                eps = torch.randn_like(x0)
+                ol, og = OTR.loss_and_grads(op, cfg, buf, x0, t, eps, None if kind == "uncond" else lq, "l2")
+                check(f"train unet {kind} step {step} loss", loss.detach(), ol, tol=1e-6)
+                worst = 0.0
+                for k, prm in m.named_parameters():
+                    g = prm.grad
+                    worst = max(worst, ((g - og[k]).abs().max() / g.abs().max().clamp_min(1e-12)).item())
+                    out[f"{kind}_s{step}_grad_sample/{k}"] = OTR.sample_of(g)
+                    out[f"{kind}_s{step}_grad_norm/{k}"] = g.norm()
+                print(f"  [train unet {kind} step {step}] gradients: oracle vs reference worst rel {worst:.3e}")
+                assert worst < 5e-5
+                out[f"{kind}_s{step}_t"], out[f"{kind}_s{step}_eps"], out[f"{kind}_s{step}_loss"] = t, eps, loss.detach()
+                opt.step()
+                opt.zero_grad()
+                OTR.adam_step(op, og, om, ov, step)
+                for k, prm in m.named_parameters():
+                    out[f"{kind}_s{step}_param_sample/{k}"] = OTR.sample_of(prm)
+    out["x0"], out["lq"] = x0, lq
+    save("train_unet", **out)
+
+
 CASES = {
+    "train_unet": case_train_unet,
     "train": case_train,
     "tiles": case_tiles,
     "metrics": case_metrics,

@@ -560,3 +560,80 @@ def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
     errs = {k: rel_err(og[k], p.grad) for k, p in d.model.named_parameters()}
     bad = {k: v for k, v in errs.items() if not v <= 1e-3}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
+
+
+@pytest.mark.parametrize("kind", ["cond", "uncond"])
+def test_unet_train_two_steps_golden(kind):
+    """Two steps of loss.backward() + Adam(lr=2e-5) on the two-level UNet the reference ran (make_golden.py::case_train_unet)."""
+    from hicdiff_amd.optim import Adam
+    from oracle.train import sample_of
+    g = golden("train_unet")
+    d = _unet_diffusion(kind, 64, (1, 2), 16)
+    d.train()
+    opt = Adam(d.parameters(), lr=2e-5)
+    x0, lq = g["x0"].cuda(), g["lq"].cuda()
+    for step in (1, 2):
+        t, eps = g[f"{kind}_s{step}_t"].cuda(), g[f"{kind}_s{step}_eps"].cuda()
+        loss = _loss(d, kind, lq, x0, t, eps)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g[f"{kind}_s{step}_loss"])) <= 1e-4 * float(g[f"{kind}_s{step}_loss"])
+        for k, p in d.model.named_parameters():
+            ref_s, ref_n = g[f"{kind}_s{step}_grad_sample/{k}"], float(g[f"{kind}_s{step}_grad_norm/{k}"])
+            got = p.grad.detach().cpu()
+            assert abs(float(got.norm()) - ref_n) <= 1e-3 * ref_n + 1e-12, (step, k)
+            scale = max(float(ref_s.abs().max()), ref_n / got.numel() ** 0.5)
+            assert float((sample_of(got) - ref_s).abs().max()) <= 1e-3 * scale, (step, k)
+        opt.step()
+        opt.zero_grad()
+        for k, p in d.model.named_parameters():
+            ref = g[f"{kind}_s{step}_param_sample/{k}"]
+            # Adam moves a parameter by ~lr per step whatever the size of its gradient, so where the gradient is tiny against its tensor's
+            # largest entry an error of 1e-3 of that entry can turn the update around: compare where the gradient is not tiny
+            gs = g[f"{kind}_s{step}_grad_sample/{k}"].abs()
+            keep = gs > 0.05 * gs.max()
+            diff = (sample_of(p.detach().cpu()) - ref).abs()
+            assert float(diff[keep].max()) <= 5e-2 * 2e-5 * step + 4e-7 * float(ref.abs().max()), (step, k)
+            assert float(diff.max()) <= 2.1 * 2e-5 * step, (step, k)                 # and nowhere by more than a turned-around update
+    assert list(d.model.state_dict().keys()) == [k for k, _ in d.model.named_parameters()]
+
+
+def test_unet_train_full_network_properties_and_loop():
+    """The full UNet (dim 64, dim_mults (1, 2, 4, 8)) at 64x64: the step repeats bit for bit, a batch's gradient is the mean of its halves',
+    and a few Adam steps on a fixed batch lower the loss; eval-mode sampling afterwards uses the updated weights."""
+    from hicdiff_amd.optim import Adam
+    d = _unet_diffusion("cond", 64, (1, 2, 4, 8), 64)
+    d.train()
+    B = 4
+    x0, lq = tiles(61, B, 64).cuda(), tiles(62, B, 64).cuda()
+    gen = torch.Generator().manual_seed(11)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()
+
+    def grads(sl):
+        for p in d.model.parameters():
+            p.grad = None
+        loss = d.p_losses([lq[sl], x0[sl]], t[sl], eps[sl])
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.clone() for k, p in d.model.named_parameters()}
+
+    l_all, g_all = grads(slice(0, B))
+    l_again, g_again = grads(slice(0, B))
+    assert l_all == l_again and all(torch.equal(g_all[k], g_again[k]) for k in g_all)
+    l_a, g_a = grads(slice(0, B // 2))
+    l_b, g_b = grads(slice(B // 2, B))
+    assert abs(l_all - 0.5 * (l_a + l_b)) <= 1e-5 * l_all
+    worst = max(rel_err(g_all[k], 0.5 * (g_a[k] + g_b[k])) for k in g_all)
+    assert worst <= 5e-4, worst
+    opt = Adam(d.parameters(), lr=2e-4)
+    before = d.model(x0, t, lq).clone()
+    losses = []
+    for _ in range(6):
+        loss = d.p_losses([lq, x0], t, eps)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.9 * losses[0], losses
+    d.eval()
+    with torch.no_grad():
+        after = d.model(x0, t, lq)
+    assert rel_err(before, after) > 1e-3

@@ -180,7 +180,6 @@ def test_cli_flags_match_the_reference():
     assert inference.create_parser().parse_args(["-u", ""]).unspervised is False
     t = train.create_parser().parse_args(["-b", "32", "-e", "3", "-l", "Dros", "-n", "2"])
     assert (t.batch_size, t.epoch, t.celline, t.celln) == (32, 3, "Dros", 2)
-    with pytest.raises(NotImplementedError):
-        train.main(["--arch", "unet", "--optimize"])          # no backward kernels for the UNet yet; hicedrn trains natively
+    assert train.create_parser().parse_args(["--arch", "unet", "--precision", "bf16"]).precision == "bf16"   # both networks train natively
     lq, hq = inference.synthetic_tiles(3, 16, 0.1, 7)
     assert lq.shape == hq.shape == (3, 1, 16, 16) and torch.equal(hq, hq.transpose(-1, -2)) and lq.abs().max() <= 1

@@ -6,10 +6,10 @@ The reference's loop (train.py:109-190): Adam(lr=2e-5) over ``diffusion.paramete
 ``no_grad``, ``bestg_*.pytorch`` on a new best validation loss, ``finalg_*.pytorch`` at the end, ``Epoch / train/loss /
 valid/loss`` logged (to wandb upstream, as JSON lines here).
 
-hicedrn (the network upstream trains, conditional and unconditional) runs the NATIVE step: forward, backward and Adam are HIP
-kernels (include/hicdiff_hip.h "training step"); under torchrun every rank takes its own batches and the flat gradient is
-all-reduced once per step (RCCL).  The UNet has no backward kernels yet: ``--arch unet`` evaluates the objective only (loss curves
-of a frozen net) unless ``--optimize`` is given, which then raises.
+Both networks run the NATIVE step -- forward, backward and Adam are HIP kernels (include/hicdiff_hip.h "training step"): hicedrn (the
+network upstream's train.py trains, conditional and unconditional) and the UNet (upstream: pretrain/train_unet_*.py).  Under torchrun every
+rank takes its own batches and the flat gradient is all-reduced once per step (RCCL).  ``--eval-only`` evaluates the objective of the
+frozen network instead.
 
 Data: ``--data-root`` points at the directory that holds ``DataFull/`` (Splits written by hicdiff_amd.processdata or by the
 reference); without it, synthetic Hi-C-like tiles.
@@ -42,7 +42,7 @@ def create_parser():
     p.add_argument("--precision", choices=["bf16x3", "bf16"], default="bf16x3",
                    help="products of the convolutions: bf16x3 = fp32-equivalent (default, the arithmetic of the parity tests); bf16 = one bf16 MFMA per "
                         "product, fp32 accumulate and fp32 master weights (mixed-precision training, ~1.8x faster)")
-    p.add_argument("--optimize", action="store_true", help="insist on the optimiser step (default for hicedrn; raises for the UNet)")
+    p.add_argument("--optimize", action="store_true", help="(kept for older command lines: the optimiser step is the default)")
     p.add_argument("--eval-only", action="store_true", help="loss curves of the frozen network, no optimiser step")
     p.add_argument("--weights-dir", default=os.path.join(ROOT, "Model_Weights"))
     p.add_argument("--seed", type=int, default=1234)
@@ -83,10 +83,9 @@ def main(argv=None):
         from hicdiff_amd.hicdiff import Unet
         net = Unet(64, dim_mults=(1, 2, 4, 8), self_condition=conditional)
     net.train_precision = args.precision
-    optimise = not args.eval_only and (args.arch == "hicedrn" or args.optimize)
+    optimise = not args.eval_only
     if optimise and not getattr(net, "_native_train", False):
-        raise NotImplementedError("the optimiser step needs backward kernels, built for hicedrn only so far (SURVEY.md section 8 row f-2); "
-                                  "run --arch unet without --optimize to evaluate the objective")
+        raise NotImplementedError("this network has no native training step; run with --eval-only to evaluate the objective")
     # HICDIFF_DEVICE / HICDIFF_DIST_BACKEND: rehearsal of the N-rank path on a one-GPU box (every rank on device 0, gloo)
     device = torch.device("cuda", int(os.environ.get("HICDIFF_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
     torch.cuda.set_device(device)
