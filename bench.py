@@ -188,7 +188,7 @@ def bench_train(args):
         from oracle import diffusion as OD, nets as ON, train as OTR
         n = 2
         sd = {k: v.detach().cpu().clone() for k, v in d.model.state_dict().items()}
-        cfg = ON.HicedrnCfg(number_resnet=blocks, self_condition=True, sr3=False)
+        cfg = ON.UnetCfg(self_condition=True) if args.train_arch == "unet" else ON.HicedrnCfg(number_resnet=blocks, self_condition=True, sr3=False)
         buf = OD.diffusion_buffers("linear", 1000)
         m, v = {k: torch.zeros_like(p) for k, p in sd.items()}, {k: torch.zeros_like(p) for k, p in sd.items()}
         c0 = time.perf_counter()
