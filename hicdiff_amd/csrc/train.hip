@@ -394,8 +394,14 @@ __global__ __launch_bounds__(256) void lin_bwd_x_kernel(const float* __restrict_
     const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     dY += blockIdx.z * dystride; W += blockIdx.z * wstride; dX += blockIdx.z * xstride;       // grid.z = layer index (per-layer partials)
-    float s = 0.f;
-    for (int n = 0; n < N; ++n) s += dY[(size_t)b * ldy + n] * W[(size_t)n * K + k];
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};                     // independent chains (see sum_rows_kernel)
+    int n = 0;
+    for (; n + 4 <= N; n += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a4[j] += dY[(size_t)b * ldy + n + j] * W[(size_t)(n + j) * K + k];
+    }
+    for (; n < N; ++n) a4[0] += dY[(size_t)b * ldy + n] * W[(size_t)n * K + k];
+    float s = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (Xpre) s *= dact_f(Xpre[(size_t)b * ldx + k], act);
     float* d = dX + (size_t)b * lddx + k;
     *d = (accumulate ? *d : 0.f) + s;
@@ -529,12 +535,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // channel-concatenated inputs are two calls with row0 = 0 and row0 = C0) or the gradient image; run() multiplies and reduces.
 struct Wgrad {
     int B = 0, H = 0, W = 0, P = 0, splitK = 1, maxCin = 0, maxCout = 0;
+    bool narrow = false;
     size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
     unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
     float* partial = nullptr;
     std::vector<void*> owned;
     void destroy() { for (void* p : owned) (void)hipFree(p); owned.clear(); }
-    bool init(int B_, int H_, int W_, int maxCin_, int maxCout_) {
+    bool init(int B_, int H_, int W_, int maxCin_, int maxCout_, bool narrow_layers = false) {
         B = B_; H = H_; W = W_; maxCin = (maxCin_ + 127) / 128 * 128; maxCout = maxCout_;
         P = ((W + 7) & ~7) + 8;
         const size_t K = ((size_t)B * (H + 1) + 1) * P;
@@ -542,7 +549,10 @@ struct Wgrad {
         const size_t max_split = getenv("HICDIFF_WG_SPLITK") ? (size_t)atoi(getenv("HICDIFF_WG_SPLITK")) : 64;
         splitK = (int)std::max<size_t>(1, std::min<size_t>(max_split, K / 2048));
         if (splitK >= 8) splitK &= ~7;
-        Kpad = (K + (size_t)64 * splitK - 1) / ((size_t)64 * splitK) * ((size_t)64 * splitK);
+        // narrow layers (one or two tiles per split) take more splits at run time (up to 4x): keep every such chunk a whole number of slices
+        const size_t quantum = (size_t)64 * splitK * (narrow_layers && splitK >= 64 ? 4 : 1);
+        narrow = narrow_layers;
+        Kpad = (K + quantum - 1) / quantum * quantum;
         kchunk = Kpad / splitK;
         guard = ((size_t)P + 72 + 63) / 64 * 64;                  // row shift (P) + one slice of read-ahead
         ld = guard + Kpad + guard;
@@ -576,14 +586,19 @@ struct Wgrad {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         const int Mt = (Cin + 127) / 128, Nt = Cout / 64, Mpad = Mt * 128;
         if (Cout % 64 || Mpad > maxCin || Cout > maxCout || (KT != 1 && KT != 3)) { hd_set_error("wgrad: unsupported shape"); return -1; }
+        // splits of this call: enough workgroups for two per CU, within the partial buffer (sized for splitK splits of the widest layer)
+        int eff = splitK;
+        if (narrow && splitK >= 64)
+            while (eff < 4 * splitK && Mt * Nt * eff < 512 && (size_t)(2 * eff) * KT * KT * Mpad * Cout <= (size_t)splitK * 9 * maxCin * maxCout) eff *= 2;
+        const size_t kch = Kpad / eff;
         // algorithmic figures: KT*KT taps x Cin x Cout outputs over the B*H*W real pixels (3 MFMA flops per product are the kernel's business);
         // bytes: both operand images once (hi + lo) + the partials
         const char* name = KT == 1 ? (plain ? "wgrad_gemm_kernel<true, true>" : "wgrad_gemm_kernel<false, true>")
                                    : (plain ? "wgrad_gemm_kernel<true>" : "wgrad_gemm_kernel<false>");
-        hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, (plain ? 1.0 : 2.0) * 2 * (Cin + Cout) * (double)Kpad + 4.0 * splitK * KT * KT * Cin * Cout, st);
-        const dim3 grid(Mt * Nt * splitK);
+        hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, (plain ? 1.0 : 2.0) * 2 * (Cin + Cout) * (double)Kpad + 4.0 * eff * KT * KT * Cin * Cout, st);
+        const dim3 grid(Mt * Nt * eff);
 #define HD_WG_LAUNCH(PLAIN_, ONE_)                                                                                          \
-        hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kchunk, splitK, Mt, Nt, Mpad, Cout, \
+        hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
                            partial, xcd_group)
         if (KT == 1) { if (plain) HD_WG_LAUNCH(true, true); else HD_WG_LAUNCH(false, true); }
         else { if (plain) HD_WG_LAUNCH(true, false); else HD_WG_LAUNCH(false, false); }
@@ -591,7 +606,7 @@ struct Wgrad {
         conv_prof_end(st);
         if (check_launch("wgrad gemm")) return -3;
         const size_t per = (size_t)KT * Mpad * KT * Cout;
-        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, splitK, Cin, Mpad, Cout, KT, scale, accumulate ? 1 : 0, dW);
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, scale, accumulate ? 1 : 0, dW);
         return check_launch("wg_reduce");
     }
 };
