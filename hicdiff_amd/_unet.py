@@ -27,8 +27,8 @@ class UnetBase(EpsNetBase):
         self.self_condition = self_condition
         self.resnet_block_groups = resnet_block_groups
         self.noise_level_emb = noise_level_emb
-        # native training step (csrc/train_unet.inc): width a multiple of 64, integer timesteps (the SR3 flavour is not covered yet)
-        self._native_train = (not noise_level_emb) and dim % 64 == 0 and len(self.dim_mults) <= 4
+        # native training step (csrc/train_unet.inc): width a multiple of 64, at most four levels
+        self._native_train = dim % 64 == 0 and len(self.dim_mults) <= 4
         self.random_or_learned_sinusoidal_cond = False
         self.out_dim = out_dim if out_dim is not None else channels
         if self.out_dim != 1:

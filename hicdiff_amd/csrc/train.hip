@@ -43,10 +43,11 @@ template <bool PLAIN>      // PLAIN: hi image only (the optional bf16 arithmetic
 __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ in, int C, int H, int W, int P, size_t ld, size_t guard,
                                                       unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int mode,
                                                       const float* __restrict__ film, int film_bs, float* __restrict__ colpart, int row0,
-                                                      const float* __restrict__ affB, int src_mode) {
+                                                      const float* __restrict__ affB, int src_mode, const float* __restrict__ affE) {
     // src_mode 0: `in` is [B][H][W][C].  1: nearest x2 upsample on the way in (Upsample, src/hicdiff.py:72-76): `in` is [B][H/2][W/2][C].
     // 2: pixel-unshuffle on the way in (Downsample, src/hicdiff.py:78-82, 'b c (h p1) (w p2) -> b (c p1 p2) h w'): `in` is [B][2H][2W][C/4]
     //    and logical channel cc = c*4 + p1*2 + p2 reads (2y + p1, 2x + p2, c).
+    // affE (mode 2 only, may be null): + affE[b*film_bs + c] AFTER the SiLU -- the SR3 blocks' additive noise embedding (src/hicdiff_sr3.py:246-251).
     // mode 0: raw; mode 1: silu(v * (film[b][c] + 1) + film[b][film_bs - C + c]) (film_bs == C: no scale) -- the hicedrn block;
     // mode 2: silu(v * film[b*film_bs + c] + affB[b*film_bs + c]) -- a GroupNorm'd, FiLM'd activation given as a per-(sample, channel) affine.
     // grid.y walks the channels in chunks of 256; row0 = first image row this tensor's channels go to (channel-concatenated inputs).
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
     // thread = (channel quad, pixel group): float4 loads (1 KB per wave), pixels pg, pg + 4, ...
     const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4, cg = cbase + c0;
     if (cg < C) {
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f), add = shf;
         if (mode == 1) {                                       // film row: [scale | shift] (film_bs == 2C) or [shift] alone (SR3, film_bs == C)
             if (film_bs == 2 * C) {
                 sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + cg);
@@ -68,6 +69,7 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
         } else if (mode == 2) {
             sc = *reinterpret_cast<const float4*>(film + (size_t)b * film_bs + cg);
             shf = *reinterpret_cast<const float4*>(affB + (size_t)b * film_bs + cg);
+            if (affE) add = *reinterpret_cast<const float4*>(affE + (size_t)b * film_bs + cg);
         }
         const float* src = in + ((size_t)(b * H + y) * W) * C + cg;
         if (src_mode == 1) src = in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2)) * C + cg;
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
                 } else {
                     v = *reinterpret_cast<const float4*>(src + (size_t)(src_mode == 1 ? x >> 1 : x) * C);
                 }
-                if (mode) { v.x = silu_f(v.x * sc.x + shf.x); v.y = silu_f(v.y * sc.y + shf.y); v.z = silu_f(v.z * sc.z + shf.z); v.w = silu_f(v.w * sc.w + shf.w); }
+                if (mode) { v.x = silu_f(v.x * sc.x + shf.x) + add.x; v.y = silu_f(v.y * sc.y + shf.y) + add.y; v.z = silu_f(v.z * sc.z + shf.z) + add.z; v.w = silu_f(v.w * sc.w + shf.w) + add.w; }
             }
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             const float e[4] = {v.x, v.y, v.z, v.w};
@@ -569,15 +571,15 @@ struct Wgrad {
         return a_hi && a_lo && b_hi && b_lo && partial;
     }
     int rewrite(const float* in, int C, int row0, bool gside, int mode, const float* film, int film_bs, const float* affB, float* colpart, bool plain,
-                hipStream_t st, int src_mode = 0) const {
+                hipStream_t st, int src_mode = 0, const float* affE = nullptr) const {
         hd_prof_begin("wg_prep_kernel", 0.0, (double)B * H * W * C * (4.0 + (plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
         const dim3 grid(B * H, (C + 255) / 256);
         if (plain)
             hipLaunchKernelGGL(wg_prep_kernel<true>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
-                               film_bs, colpart, row0, affB, src_mode);
+                               film_bs, colpart, row0, affB, src_mode, affE);
         else
             hipLaunchKernelGGL(wg_prep_kernel<false>, grid, dim3(256), 0, st, in, C, H, W, P, ld, guard, gside ? b_hi : a_hi, gside ? b_lo : a_lo, mode, film,
-                               film_bs, colpart, row0, affB, src_mode);
+                               film_bs, colpart, row0, affB, src_mode, affE);
         conv_prof_end(st);
         return check_launch("wg_prep");
     }
@@ -684,7 +686,6 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     if (!out || !a) return HD_EINVAL;
     *out = nullptr;
     if (a->kind == HD_ARCH_UNET) {
-        if (a->sr3) return tfail(nullptr, HD_EINVAL, "native training of the SR3 UNet is not built yet");
         if (a->dim % 64 || a->n_mults < 1 || a->n_mults > 4 || B < 1 || S < 8 || S > 64 || (S >> (a->n_mults - 1)) < 4 || S % (1 << (a->n_mults - 1)))
             return tfail(nullptr, HD_EINVAL, "UNet training: dim a multiple of 64, at most 4 levels, 8 <= S <= 64 divisible by 2^(levels-1)");
         if (hipSetDevice(device) != hipSuccess) return tfail(nullptr, HD_EHIP, "hipSetDevice failed");
@@ -820,9 +821,9 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     if (!tr || !params || !grads || !x_start || !t || !noise || !a_t || !s_t || !loss) return HD_EINVAL;
     if (tr->unet) {
         if ((tr->arch.self_condition != 0) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
-        if (t_kind != HD_T_INT64) return tfail(tr, HD_EINVAL, "the UNet takes integer timesteps");
+        if ((t_kind == HD_T_FLOAT32) != (tr->arch.sr3 != 0)) return tfail(tr, HD_EINVAL, "SR3 nets take the continuous noise level (float32); the others integer timesteps");
         tr->err.clear();
-        const int rc = tr->unet->step(params, grads, x_start, cond, t, noise, a_t, s_t, l2, loss, (hipStream_t)stream);
+        const int rc = tr->unet->step(params, grads, x_start, cond, t, noise, a_t, s_t, l2, loss, (hipStream_t)stream);   // t: int64 steps, or float levels (SR3)
         return rc == 0 ? HD_OK : tfail(tr, rc == -4 ? HD_ENOMEM : HD_EHIP, "UNet training step: " + (tr->unet->why.empty() ? std::string("a launch failed") : tr->unet->why));
     }
     if ((tr->cin0 == 2) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");

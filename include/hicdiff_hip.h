@@ -210,8 +210,8 @@ int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, 
  * train.py:109-134 with torch autograd (p_losses src/hicdiff.py:711-747, src/hicdiff_condition.py:715-746; net
  * src/model/hicedrn_Diff.py:169-289; optim.Adam(lr=2e-5) train.py:111).  The caller owns four flat fp32 device arrays
  * (params, grads, and Adam's m, v) laid out as hd_train_param_slot describes: the reference's state_dict order, every tensor
- * in torch layout at a 16-byte aligned offset.  Covers hicedrn_Diff (unconditional, self_condition) and its SR3 flavour
- * (src/model/hicedrn_sr3_Diff.py:245-352); the UNet is not covered yet (hd_train_create returns HD_EINVAL). */
+ * in torch layout at a 16-byte aligned offset.  Covers both eps-networks in their three flavours: hicedrn_Diff (src/model/hicedrn_Diff.py,
+ * hicedrn_sr3_Diff.py) and the UNet (src/hicdiff.py, hicdiff_condition.py, hicdiff_sr3.py; width a multiple of 64, at most four levels). */
 typedef struct hd_trainer hd_trainer;
 
 /* Sizes the saved activations for batches of exactly B tiles of 1xSxS (two tensors of B*S*S*256 floats per residual block). */

@@ -504,10 +504,12 @@ def case_train_unet():
     out = {}
     B, S, T = 2, 16, 1000
     x0, lq = tiles(23, B, S), tiles(24, B, S)
-    for kind in ("cond", "uncond"):
+    for kind in ("cond", "uncond", "sr3"):
         m, cfg = build_unet(kind, dim=64, mults=(1, 2))
         m.train()
-        d = (R1 if kind == "cond" else R0).GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        T = 2000 if kind == "sr3" else 1000
+        d = {"cond": R1, "uncond": R0, "sr3": R2}[kind].GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+        oref = OD.DiffusionRef(None, image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="sr3") if kind == "sr3" else None
         names = [k for k, _ in m.named_parameters()]
         sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
         buf = OD.diffusion_buffers("linear", T)
@@ -516,11 +518,12 @@ def case_train_unet():
         op = {k: sd[k].clone() for k in names}
         with torch.enable_grad():
             for step in (1, 2):
+                np.random.seed(80 + step)
                 torch.manual_seed(400 + step)
                 loss = d(x0 if kind == "uncond" else [lq, x0])
                 loss.backward()
                 torch.manual_seed(400 + step)
-                t = torch.randint(0, T, (B,)).long()
+                t = oref.sr3_draw_level(np.random.RandomState(80 + step), B) if kind == "sr3" else torch.randint(0, T, (B,)).long()
                 eps = torch.randn_like(x0)
                 ol, og = OTR.loss_and_grads(op, cfg, buf, x0, t, eps, None if kind == "uncond" else lq, "l2")
                 check(f"train unet {kind} step {step} loss", loss.detach(), ol, tol=1e-6)

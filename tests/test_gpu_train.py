@@ -536,22 +536,25 @@ def _unet_diffusion(kind, dim, mults, S, loss="l2"):
     m = product_unet(kind, dim=dim, mults=mults)
     if kind == "cond":
         from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+    elif kind == "sr3":
+        from hicdiff_amd.hicdiff_sr3 import GaussianDiffusion
     else:
         from hicdiff_amd.hicdiff import GaussianDiffusion
-    return GaussianDiffusion(m, image_size=S, timesteps=1000, loss_type=loss, beta_schedule="linear").cuda()
+    return GaussianDiffusion(m, image_size=S, timesteps=2000 if kind == "sr3" else 1000, loss_type=loss, beta_schedule="linear").cuda()
 
 
-@pytest.mark.parametrize("kind,dim,mults,B,S", [("cond", 64, (1, 2), 2, 16), ("uncond", 64, (1, 2, 4), 2, 32)])
+@pytest.mark.parametrize("kind,dim,mults,B,S", [("cond", 64, (1, 2), 2, 16), ("uncond", 64, (1, 2, 4), 2, 32), ("sr3", 64, (1, 2), 3, 16)])
 def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
     """The UNet's native training step: every entry of every gradient against torch autograd over the oracle net (CPU fp32)."""
     from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
     d = _unet_diffusion(kind, dim, mults, S)
     d.train()
-    cfg = ON.UnetCfg(dim=dim, dim_mults=tuple(mults), self_condition=(kind != "uncond"), sr3=False)
-    sd = W.fill_state_dict(W.unet_shapes(dim=dim, dim_mults=tuple(mults), self_condition=cfg.self_condition, sr3=False))
+    cfg = ON.UnetCfg(dim=dim, dim_mults=tuple(mults), self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    sd = W.fill_state_dict(W.unet_shapes(dim=dim, dim_mults=tuple(mults), self_condition=cfg.self_condition, sr3=cfg.sr3))
     x0, lq = tiles(51, B, S), tiles(52, B, S)
     gen = torch.Generator().manual_seed(7)
-    t, eps = torch.randint(0, 1000, (B,), generator=gen), torch.randn(x0.shape, generator=gen)
+    t = torch.rand((B,), generator=gen) * 0.9 + 0.05 if kind == "sr3" else torch.randint(0, 1000, (B,), generator=gen)
+    eps = torch.randn(x0.shape, generator=gen)
     ol, og = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("linear", 1000), x0, t, eps, None if kind == "uncond" else lq, "l2")
     val = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
     assert val.requires_grad
@@ -562,7 +565,7 @@ def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
 
 
-@pytest.mark.parametrize("kind", ["cond", "uncond"])
+@pytest.mark.parametrize("kind", ["cond", "uncond", "sr3"])
 def test_unet_train_two_steps_golden(kind):
     """Two steps of loss.backward() + Adam(lr=2e-5) on the two-level UNet the reference ran (make_golden.py::case_train_unet)."""
     from hicdiff_amd.optim import Adam

@@ -227,16 +227,16 @@ def test_train_oracle_reproduces_reference_gradients_and_adam(kind):
             assert float((OTR.sample_of(sd[k]) - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-9, (step, k)
 
 
-@pytest.mark.parametrize("kind", ["cond", "uncond"])
+@pytest.mark.parametrize("kind", ["cond", "uncond", "sr3"])
 def test_train_oracle_reproduces_reference_unet_gradients(kind):
     """oracle/train.py on the two-level UNet against the reference's own loss.backward() (make_golden.py::case_train_unet), first step."""
     from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
     g = np.load(os.path.join(GOLDEN, "train_unet.npz"))
-    cfg = ON.UnetCfg(dim=64, dim_mults=(1, 2), self_condition=(kind == "cond"), sr3=False)
-    sd = W.fill_state_dict(W.unet_shapes(dim=64, dim_mults=(1, 2), self_condition=cfg.self_condition, sr3=False))
+    cfg = ON.UnetCfg(dim=64, dim_mults=(1, 2), self_condition=(kind != "uncond"), sr3=(kind == "sr3"))
+    sd = W.fill_state_dict(W.unet_shapes(dim=64, dim_mults=(1, 2), self_condition=cfg.self_condition, sr3=cfg.sr3))
     x0, lq = torch.from_numpy(g["x0"]), torch.from_numpy(g["lq"])
     t, eps = torch.from_numpy(g[f"{kind}_s1_t"]), torch.from_numpy(g[f"{kind}_s1_eps"])
-    loss, grads = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("linear", 1000), x0, t, eps, lq if kind == "cond" else None, "l2")
+    loss, grads = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("linear", 1000), x0, t, eps, None if kind == "uncond" else lq, "l2")
     assert abs(float(loss) - float(g[f"{kind}_s1_loss"])) <= 1e-6 * float(loss)
     for k in sd:
         ref = torch.from_numpy(g[f"{kind}_s1_grad_sample/{k}"])
