@@ -640,3 +640,13 @@ def test_unet_train_full_network_properties_and_loop():
     with torch.no_grad():
         after = d.model(x0, t, lq)
     assert rel_err(before, after) > 1e-3
+
+
+def test_train_cli_unet(tmp_path, capsys):
+    """train.py --arch unet: the full UNet (64, (1,2,4,8)) trains natively on 32x32 tiles; loss falls; checkpoints carry the Unet tag."""
+    import json
+    import train
+    train.main(["-u", "", "-b", "4", "-e", "3", "--arch", "unet", "--tile", "32", "--tiles-per-epoch", "16", "--lr", "3e-4", "--weights-dir", str(tmp_path)])
+    lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 3 and lines[-1]["train/loss"] < 0.9 * lines[0]["train/loss"], lines
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["bestg_40000_c64_s32_Human1_Unet_cond_l2_lin.pytorch", "finalg_40000_c64_s32_Human1_Unet_cond_l2_lin.pytorch"]
