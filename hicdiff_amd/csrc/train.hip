@@ -572,6 +572,7 @@ struct Wgrad {
     }
     int rewrite(const float* in, int C, int row0, bool gside, int mode, const float* film, int film_bs, const float* affB, float* colpart, bool plain,
                 hipStream_t st, int src_mode = 0, const float* affE = nullptr) const {
+        if (row0 + C > (gside ? maxCout : maxCin) || C % 4) { hd_set_error("wgrad rewrite: the operand image has too few rows for this tensor"); return -1; }
         hd_prof_begin("wg_prep_kernel", 0.0, (double)B * H * W * C * (4.0 + (plain ? 2.0 : 4.0)), st);   // fp32 in, bf16 hi (+ lo) out
         const dim3 grid(B * H, (C + 255) / 256);
         if (plain)
