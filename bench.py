@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: denoised Hi-C tiles / second for a 1000-step reverse (ancestral DDPM) chain.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload unet64|unet40|hicedrn64|unet64cond]
+    python bench.py [--gpus N --steps K --warmup W] [--workload unet64|unet40|hicedrn64|unet64cond|hicedrn64cond]
     python bench.py --workload hicedrn64_train [--batch 64 --steps 5 --warmup 2]     (native training step)
     python bench.py --workload tiles                                                (tile producer / stitcher, section 8 f-3)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -34,6 +34,7 @@ WORK = {
     "unet64cond": dict(arch="unet", cond=True, S=64, B=256, flop=14.384e9, act_bytes=92.6e6, w_bytes=142.8e6),
     "unet40": dict(arch="unet", cond=False, S=40, B=64, flop=5.611e9, act_bytes=36.2e6, w_bytes=142.7e6),
     "hicedrn64": dict(arch="hicedrn", cond=False, S=64, B=256, flop=314.143e9, act_bytes=553.7e6, w_bytes=150.3e6),
+    "hicedrn64cond": dict(arch="hicedrn", cond=True, S=64, B=256, flop=314.162e9, act_bytes=553.7e6, w_bytes=150.3e6),   # + the second input plane of the head
 }
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA; the split-bf16 x3 conv issues 3 MFMA flops per algorithmic flop
@@ -66,9 +67,12 @@ def build_model(w, device):
             from hicdiff_amd.hicdiff import GaussianDiffusion, Unet
             net = Unet(64, dim_mults=(1, 2, 4, 8))
     else:
-        from hicdiff_amd.hicdiff import GaussianDiffusion
         from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
-        net = hicedrn_Diff()
+        if w["cond"]:
+            from hicdiff_amd.hicdiff_condition import GaussianDiffusion
+        else:
+            from hicdiff_amd.hicdiff import GaussianDiffusion
+        net = hicedrn_Diff(self_condition=w["cond"])
     net = net.to(device)
     diff = GaussianDiffusion(net, image_size=w["S"], timesteps=T_CHAIN, loss_type="l2", beta_schedule="linear").to(device)
     return net, diff
@@ -89,8 +93,8 @@ def cpu_baseline(w, budget_s=20.0):
         sd = W.fill_state_dict(W.unet_shapes(self_condition=w["cond"]))
         bs = 8
     else:
-        cfg = ON.HicedrnCfg()
-        sd = W.fill_state_dict(W.hicedrn_shapes())
+        cfg = ON.HicedrnCfg(self_condition=w["cond"])
+        sd = W.fill_state_dict(W.hicedrn_shapes(self_condition=w["cond"]))
         bs = 1
     model = ON.make_eps_fn(sd, cfg)
     kind = "cond" if w["cond"] else "uncond"
