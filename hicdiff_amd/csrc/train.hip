@@ -53,12 +53,14 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
     // grid.y walks the channels in chunks of 256; row0 = first image row this tensor's channels go to (channel-concatenated inputs).
     constexpr int PITCH = 68;                                  // ushorts per channel row: 136 B, 8-byte aligned, 2-way conflicts at most
     __shared__ __attribute__((aligned(16))) unsigned short sh_hi[256 * PITCH], sh_lo[256 * PITCH];
-    __shared__ float csum[4][256];
+    __shared__ float csum[1024];                                // [pixel groups][channels of this chunk]
     const int b = blockIdx.x / H, y = blockIdx.x % H, tid = threadIdx.x, cbase = blockIdx.y * 256;
     const int W8 = (W + 7) & ~7;
-    // thread = (channel quad, pixel group): float4 loads (1 KB per wave), pixels pg, pg + 4, ...
-    const int cq = tid & 63, pgp = tid >> 6, c0 = cq * 4, cg = cbase + c0;
-    if (cg < C) {
+    // thread = (channel quad, pixel group): float4 loads; a chunk of cc channels has cc/4 quads and 256 / (cc/4) pixel groups, so narrow
+    // layers (64, 128 channels -- the full-resolution levels of the UNet) keep all 256 threads loading
+    const int cc = min(256, C - cbase), nq = cc >> 2, npg = 256 / nq;       // cc is a multiple of 4 and, for cc < 256, a power-of-two multiple of 64 in practice
+    const int cq = tid % nq, pgp = tid / nq, c0 = cq * 4, cg = cbase + c0;
+    if (pgp < npg) {
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), shf = make_float4(0.f, 0.f, 0.f, 0.f), sum = make_float4(0.f, 0.f, 0.f, 0.f), add = shf;
         if (mode == 1) {                                       // film row: [scale | shift] (film_bs == 2C) or [shift] alone (SR3, film_bs == C)
             if (film_bs == 2 * C) {
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
         const float* src = in + ((size_t)(b * H + y) * W) * C + cg;
         if (src_mode == 1) src = in + ((size_t)(b * (H / 2) + (y >> 1)) * (W / 2)) * C + cg;
         const int Cs = C / 4, cs = cg >> 2;                    // unshuffle: source channels, this quad's source channel
-        for (int x = pgp; x < W8; x += 4) {
+        for (int x = pgp; x < W8; x += npg) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);       // columns W .. W8-1 of the last 8-pixel group stay zero (they are padding)
             if (x < W) {
                 if (src_mode == 2) {
@@ -95,10 +97,14 @@ __global__ __launch_bounds__(256) void wg_prep_kernel(const float* __restrict__ 
                 if constexpr (!PLAIN) sh_lo[(c0 + j) * PITCH + x] = __builtin_bit_cast(unsigned short, ll);
             }
         }
-        csum[pgp][c0] = sum.x; csum[pgp][c0 + 1] = sum.y; csum[pgp][c0 + 2] = sum.z; csum[pgp][c0 + 3] = sum.w;
+        csum[pgp * cc + c0] = sum.x; csum[pgp * cc + c0 + 1] = sum.y; csum[pgp * cc + c0 + 2] = sum.z; csum[pgp * cc + c0 + 3] = sum.w;
     }
     __syncthreads();
-    if (colpart && cbase + tid < C) colpart[(size_t)blockIdx.x * C + cbase + tid] = (csum[0][tid] + csum[1][tid]) + (csum[2][tid] + csum[3][tid]);
+    if (colpart && tid < cc) {
+        float t = 0.f;
+        for (int g = 0; g < npg; ++g) t += csum[g * cc + tid];
+        colpart[(size_t)blockIdx.x * C + cbase + tid] = t;
+    }
     const int xg = tid & 7;
     const size_t kbase = guard + ((size_t)b * (H + 1) + y + 1) * P + 8 + xg * 8;
     if (xg * 8 < W8) {
