@@ -436,10 +436,12 @@ __global__ __launch_bounds__(256) void sin_emb_kernel(const void* __restrict__ t
 // ---- first / last convolution weight gradients (1-2 channels on one side) -----------------------------------------------
 // part[(b*nrb + rb)][c][j*KS*KS + tap] = sum over the row block of big[p][c] * small_j[p + sign*(tap offset)]
 // KS = 3 (hicedrn head / tail) or 7 (the UNet's init_conv, src/hicdiff.py:279).
-template <int KS>
+// NG: threads per channel, each taking every NG-th tap (the UNet's first convolution has 64 output channels and 49 taps: 4 x 13 taps per channel
+// keep the workgroup's 256 threads busy); C * NG <= 256 or NG == 1.
+template <int KS, int NG>
 __global__ __launch_bounds__(256) void small_conv_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ s0, const float* __restrict__ s1,
                                                                int J, int S, int C, int RB, int sign, float* __restrict__ part) {
-    constexpr int R = KS / 2, T = KS * KS;
+    constexpr int R = KS / 2, T = KS * KS, TP = (T + NG - 1) / NG;
     extern __shared__ float sm[];                           // [J][RB + 2R][S + 2R]
     const int b = blockIdx.y, rb = blockIdx.x, nrb = gridDim.x, y0 = rb * RB, LW = S + 2 * R, LH = RB + 2 * R;
     for (int i = threadIdx.x; i < J * LH * LW; i += 256) {
@@ -449,21 +451,30 @@ __global__ __launch_bounds__(256) void small_conv_wgrad_kernel(const float* __re
         sm[i] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? src[((size_t)b * S + yy) * S + xx] : 0.f;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        for (int j = 0; j < J; ++j) {                       // one small plane at a time: T accumulators per thread
-            float acc[T];
+    const int tg = NG == 1 ? 0 : (int)threadIdx.x / C;
+    if (NG > 1 && tg >= NG) return;
+    for (int c = NG == 1 ? threadIdx.x : (int)threadIdx.x % C; c < C; c += NG == 1 ? 256 : C) {
+        for (int j = 0; j < J; ++j) {                       // one small plane at a time: TP accumulators per thread
+            float acc[TP];
+            int off[TP];
 #pragma unroll
-            for (int t = 0; t < T; ++t) acc[t] = 0.f;
+            for (int i = 0; i < TP; ++i) {
+                const int t = min(tg + i * NG, T - 1);       // (a clamped duplicate tap is computed and dropped below)
+                acc[i] = 0.f;
+                off[i] = (j * LH + R + sign * (t / KS - R)) * LW + R + sign * (t % KS - R);
+            }
             for (int yy = 0; yy < RB && y0 + yy < S; ++yy)
                 for (int x = 0; x < S; ++x) {
                     const float v = big[(((size_t)b * S + y0 + yy) * S + x) * C + c];
+                    const float* row = sm + yy * LW + x;
 #pragma unroll
-                    for (int t = 0; t < T; ++t) acc[t] += v * sm[(j * LH + yy + R + sign * (t / KS - R)) * LW + x + R + sign * (t % KS - R)];
+                    for (int i = 0; i < TP; ++i) acc[i] += v * row[off[i]];
                 }
             float* d = part + ((size_t)(b * nrb + rb) * C + c) * (J * T) + j * T;
 #pragma unroll
-            for (int t = 0; t < T; ++t) d[t] = acc[t];
+            for (int i = 0; i < TP; ++i) { const int t = tg + i * NG; if (t < T) d[t] = acc[i]; }
         }
+        if (NG > 1) break;
     }
 }
 
@@ -894,7 +905,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     // ---- backward
     const int RB = 8, nrb = (S + RB - 1) / RB;
     // tail: dW[0][ci][tap] = sum_p Y[p + tap][ci] dout[p]; db = sum dout; dY = conv(dout, flipped tail weight)
-    hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), (size_t)(RB + 2) * (S + 2) * sizeof(float), st, tr->Y, tr->dout, (const float*)nullptr, 1, S, F, RB,
+    hipLaunchKernelGGL((small_conv_wgrad_kernel<3, 1>), dim3(nrb, B), dim3(256), (size_t)(RB + 2) * (S + 2) * sizeof(float), st, tr->Y, tr->dout, (const float*)nullptr, 1, S, F, RB,
                        -1, tr->spart);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9, 1.f, 0, grads + tr->o_tail_w);
     TR_TRY(check_launch("tail wgrad"));
@@ -934,7 +945,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     // head: d(head output) = dx + dY (the skip r); dW[co][cin][tap] = sum_p in_cin[p + tap] d[p][co]
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, dY, n4, da);
     const float* s0 = tr->cin0 == 2 ? cond : tr->xt;
-    hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), (size_t)tr->cin0 * (RB + 2) * (S + 2) * sizeof(float), st, da, s0, tr->xt, tr->cin0, S, F,
+    hipLaunchKernelGGL((small_conv_wgrad_kernel<3, 1>), dim3(nrb, B), dim3(256), (size_t)tr->cin0 * (RB + 2) * (S + 2) * sizeof(float), st, da, s0, tr->xt, tr->cin0, S, F,
                        RB, 1, tr->spart);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F * 9 * tr->cin0 + 255) / 256, 1), dim3(256), 0, st, tr->spart, B * nrb, F * 9 * tr->cin0, 1.f, 0, grads + tr->o_head_w);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F + 255) / 256, B * S), dim3(256), 0, st, da, S, F, 1.f, 0, tr->colpart);
@@ -973,8 +984,10 @@ extern "C" int hd_adam_step(float* params, const float* grads, float* m, float* 
 int launch_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* scratch, float* dW, hipStream_t st) {
     const int RB = 8, nrb = (S + RB - 1) / RB, R = KS / 2, T = KS * KS;
     const size_t lds = (size_t)J * (RB + 2 * R) * (S + 2 * R) * sizeof(float);
-    if (KS == 7) hipLaunchKernelGGL(small_conv_wgrad_kernel<7>, dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
-    else if (KS == 3) hipLaunchKernelGGL(small_conv_wgrad_kernel<3>, dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    if (KS == 7 && C == 64) hipLaunchKernelGGL((small_conv_wgrad_kernel<7, 4>), dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    else if (KS == 7 && C == 128) hipLaunchKernelGGL((small_conv_wgrad_kernel<7, 2>), dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    else if (KS == 7) hipLaunchKernelGGL((small_conv_wgrad_kernel<7, 1>), dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
+    else if (KS == 3) hipLaunchKernelGGL((small_conv_wgrad_kernel<3, 1>), dim3(nrb, B), dim3(256), lds, st, g, in0, in1, J, S, C, RB, 1, scratch);
     else { hd_set_error("first-conv weight gradient: 3x3 or 7x7"); return -1; }
     hipLaunchKernelGGL(sum_rows_kernel, dim3((C * J * T + 255) / 256, 1), dim3(256), 0, st, scratch, B * nrb, C * J * T, 1.f, 0, dW);
     return check_launch("first conv wgrad");
