@@ -193,24 +193,34 @@ int conv_splitk(const ConvArgs& a) {
     return (nch + kchunks - 1) / kchunks;          // every split non-empty
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t n4, const float* __restrict__ bias, int Cout,
-                                                            float* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n4) return;
-    float4 s = reinterpret_cast<const float4*>(ws)[i];
-    for (int k = 1; k < nsplit; ++k) {
-        const float4 v = reinterpret_cast<const float4*>(ws)[(size_t)k * n4 + i];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+// out[b][p][c] = bias[c] + sum_split ws[split][b][p][c] in a fixed order; gn_part (optional): the GroupNorm partial sums of the finished
+// output in the one-slot form gn_finalize reads ([b][0][c] = (sum, sum of squares) over the sample's pixels).  The maps that take this
+// path have at most 128 pixels; Cout is a multiple of 64.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t per_split, const float* __restrict__ bias, int HW,
+                                                            int Cout, float* __restrict__ out, float* __restrict__ gn_part) {
+    // workgroup = (sample, 64 channels); thread = (channel, one of four pixel groups): 256-byte rows, four pixels in flight per channel
+    __shared__ float r1[4][64], r2[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, pg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+    const float bv = bias ? bias[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = pg; p < HW; p += 4) {
+        const size_t e = ((size_t)b * HW + p) * Cout + c;
+        float v = ws[e];
+        for (int k = 1; k < nsplit; ++k) v += ws[(size_t)k * per_split + e];
+        v += bv;
+        out[e] = v;
+        s1 += v; s2 += v * v;
     }
-    if (bias) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + (i * 4) % Cout);
-        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
-    }
-    reinterpret_cast<float4*>(out)[i] = s;
+    if (!gn_part) return;
+    r1[pg][cl] = s1; r2[pg][cl] = s2;
+    __syncthreads();
+    if (pg == 0)
+        *reinterpret_cast<float2*>(gn_part + ((size_t)b * Cout + c) * 2) =
+            make_float2((r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]), (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]));
 }
 
 int conv_gn_slots(const ConvArgs& a) {
-    if (conv_splitk(a) > 1) return 0;             // the partial sums are not final in the convolution's epilogue
+    if (conv_splitk(a) > 1) return 1;             // one slot per sample, written by the split-K reduce (which sees the finished output)
     const ConvPlan pl = plan_conv(a);
     if (!gn_in_epilogue(pl)) return 0;
     return ((a.H + pl.g.TH - 1) / pl.g.TH) * ((a.W + pl.g.TW - 1) / pl.g.TW);
@@ -268,12 +278,12 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
         k.ksplit = ks; k.kchunks = (nch + ks - 1) / ks;
         k.split_stride = (unsigned long long)a.B * a.H * a.W * k.Cout;
         k.out = a.splitk_ws; k.bias = nullptr; k.gn_part = nullptr; k.gn_slots = 0;
-        if (gn_slots_out) *gn_slots_out = 0;
+        if (gn_slots_out) *gn_slots_out = a.gn_part ? 1 : 0;
         if (k.Cout != k.CoutPad) { hd_set_error("conv: split-K needs Cout a multiple of 64"); return -1; }
         const int rc = launch_conv_bf16x3(L, st);
         if (rc) return rc;
-        const size_t n4 = (size_t)k.split_stride / 4;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, a.splitk_ws, ks, n4, a.cw.bias, k.Cout, a.out);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(k.Cout / 64, a.B), dim3(256), 0, st, a.splitk_ws, ks, (size_t)k.split_stride, a.cw.bias, a.H * a.W,
+                           k.Cout, a.out, a.gn_part);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { hd_set_error(std::string("splitk_reduce: ") + hipGetErrorString(e)); return -3; }
         return 0;
