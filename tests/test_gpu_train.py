@@ -543,7 +543,8 @@ def _unet_diffusion(kind, dim, mults, S, loss="l2"):
     return GaussianDiffusion(m, image_size=S, timesteps=2000 if kind == "sr3" else 1000, loss_type=loss, beta_schedule="linear").cuda()
 
 
-@pytest.mark.parametrize("kind,dim,mults,B,S", [("cond", 64, (1, 2), 2, 16), ("uncond", 64, (1, 2, 4), 2, 32), ("sr3", 64, (1, 2), 3, 16)])
+@pytest.mark.parametrize("kind,dim,mults,B,S", [("cond", 64, (1, 2), 2, 16), ("uncond", 64, (1, 2, 4), 2, 32), ("sr3", 64, (1, 2), 3, 16),
+                                                ("cond", 64, (1, 2, 4, 8), 2, 40)])   # the full UNet on 40x40 tiles: maps of 40, 20, 10 and 5 pixels
 def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
     """The UNet's native training step: every entry of every gradient against torch autograd over the oracle net (CPU fp32)."""
     from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
