@@ -170,6 +170,75 @@ def test_sharded_sampling_world_size_2_gloo(tmp_path):
         assert b"ok" in out
 
 
+_TRAIN_WORKER = r"""
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+import hicdiff_amd.optim as O
+
+calls = []
+class FakeLib:                                   # the HIP library is not needed for the collective logic: record what Adam.step would launch
+    def hd_adam_step(self, p, g, m, v, n, lr, b1, b2, eps, step, scale, st):
+        calls.append((n, lr, step, scale))
+        return 0
+O.L.load = lambda: FakeLib()
+class FakeStream:
+    cuda_stream = 0
+class FakeCtx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+torch.cuda.device = lambda d: FakeCtx()
+torch.cuda.current_stream = lambda: FakeStream()
+
+class FakeTrainer:                               # what optim.Adam touches of a NativeTrainer
+    def __init__(self, model):
+        self.model, self.device = model, torch.device("cpu")
+        self.flat = torch.arange(8, dtype=torch.float32)
+        self.grads = torch.full((8,), float(rank + 1))          # rank 0: ones, rank 1: twos
+        self.params = []
+        self.changed = 0
+    def grad_view(self, i): return self.grads[4 * i:4 * i + 4]
+    def weights_changed(self): self.changed += 1
+model = object()
+tr = FakeTrainer(model)
+for i in range(2):
+    p = torch.nn.Parameter(tr.flat[4 * i:4 * i + 4].clone())
+    p._hd_flat = (tr, 4 * i)
+    p.grad = tr.grad_view(i)
+    tr.params.append(p)
+opt = O.Adam(tr.params, lr=2e-5)
+opt.step()
+assert torch.equal(tr.grads, torch.full((8,), 3.0)), tr.grads            # summed over the two ranks by ONE all-reduce of the flat buffer
+assert calls == [(8, 2e-5, 1, 0.5)], calls                                # the mean is taken inside the Adam kernel: scale = 1 / world
+assert tr.changed == 1
+opt.zero_grad()
+assert all(p.grad is None for p in tr.params)
+opt.step()                                                               # nothing back-propagated since zero_grad: no launch, no collective
+assert len(calls) == 1
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_training_gradient_all_reduce_world_size_2_gloo(tmp_path):
+    """The N-rank glue of the training step (hicdiff_amd/optim.py) on CPU: one all-reduce of the flat gradient buffer per step, the 1/world
+    folded into the Adam launch, no launch after zero_grad.  The HIP library is replaced by a recorder (the kernels are covered on the GPU)."""
+    script = tmp_path / "train_worker.py"
+    script.write_text(_TRAIN_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+        assert b"ok" in out
+
+
 def test_cli_flags_match_the_reference():
     """train.py / inference.py keep the reference's six flags, defaults and bool-typed -u quirk."""
     import inference
