@@ -4,12 +4,16 @@
     python bench.py [--gpus N --steps K --warmup W] [--workload unet64|unet40|hicedrn64|unet64cond|hicedrn64cond]
     python bench.py --workload hicedrn64_train [--batch 64 --steps 5 --warmup 2]     (native training step)
     python bench.py --workload tiles                                                (tile producer / stitcher, section 8 f-3)
+    python bench.py --gpus N                       (N > 1 without RANK in the environment: starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --full-chain                   (time all 1000 steps of one chain; also implied by --steps >= 1000)
 
 A "step" is one pass of the hot path over one batch: the epsilon-network forward plus the fused
 posterior update for B tiles (one hd_ddpm_step call).  All steps of a chain cost the same, so
-tiles/s for a full chain = tiles per batch / (1000 * seconds per step).  Tiles shard across ranks
+tiles/s for a full chain = tiles per batch / (1000 * seconds per step).  Because the chip lowers its
+clock under sustained MFMA load, the line also carries `sustained`: a whole 1000-step chain (or as much
+of one as fits the time budget) timed after the K-step region, next to the K-step figure.  Tiles shard across ranks
 with no data-path collective (weak scaling: B tiles per GPU); the one RCCL all-gather of the
 finished tiles is exercised after the timed region and reported separately.
 
@@ -57,6 +61,44 @@ def recorded_traffic(workload, kernel, batch, default_batch):
     return None, None
 
 
+def rank_env(args):
+    """(rank, local device index, world, dist-or-None).  HICDIFF_BENCH_BACKEND=gloo and HICDIFF_DEVICE=<i> let several ranks
+    rehearse on one GPU (tests); the default is one GPU per rank over RCCL."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = int(os.environ.get("HICDIFF_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("HICDIFF_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, device, world, dist
+
+
+def max_over_ranks(seconds, dist, device):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def host_threads():
+    """CPU-baseline threads: the cores this job may use, capped at the GPU box's share of 16 per GPU (HICDIFF_CPU_THREADS overrides)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, int(os.environ.get("HICDIFF_CPU_THREADS", "16"))))
+
+
 def build_model(w, device):
     torch.manual_seed(1234)
     if w["arch"] == "unet":
@@ -82,11 +124,7 @@ def cpu_baseline(w, budget_s=20.0):
     """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample:
     the same step (eps-net + posterior update) on a small batch of the same tile size."""
     from oracle import diffusion as OD, nets as ON, weights as W
-    try:
-        cores = len(os.sched_getaffinity(0))       # the cores this job may use, not the host's total
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("HICDIFF_CPU_THREADS", "16"))))   # GPU-box share: 16 cores per GPU
+    cores = host_threads()
     torch.set_num_threads(cores)
     if w["arch"] == "unet":
         cfg = ON.UnetCfg(self_condition=w["cond"])
@@ -124,16 +162,7 @@ def bench_train(args):
     """--workload hicedrn64_train: training tiles / second of the native hicedrn step.
     A step = `loss = diffusion([lq, hq]); loss.backward(); optimizer.step(); optimizer.zero_grad()` (train.py:120-134) on synthetic
     tiles resident in HBM; data parallel under torchrun (one all-reduce of the flat gradient per step), weak scaling."""
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(dev)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rank, dev, world, dist = rank_env(args)
     from hicdiff_amd.hicdiff_condition import GaussianDiffusion
     from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
     from hicdiff_amd.optim import Adam
@@ -172,11 +201,7 @@ def bench_train(args):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    dt = max_over_ranks(time.perf_counter() - t0, dist, dev)
     # per-kernel durations: one more step with a HIP event pair around every convolution / GEMM / rewrite launch
     from hicdiff_amd import _lib as L
     lib = L.load()
@@ -191,6 +216,7 @@ def bench_train(args):
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import diffusion as OD, nets as ON, train as OTR
         n = 2
+        torch.set_num_threads(host_threads())
         sd = {k: v.detach().cpu().clone() for k, v in d.model.state_dict().items()}
         cfg = ON.UnetCfg(self_condition=True) if args.train_arch == "unet" else ON.HicedrnCfg(number_resnet=blocks, self_condition=True, sr3=False)
         buf = OD.diffusion_buffers("linear", 1000)
@@ -309,7 +335,16 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="tiles per GPU (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
+    ap.add_argument("--full-chain", action="store_true", help="time a whole chain: --steps becomes 1000 (t = 999 .. 0)")
+    ap.add_argument("--sustained-budget", type=float, default=45.0,
+                    help="seconds the post-timing sustained run may take (a whole 1000-step chain when it fits; 0 disables)")
     args = ap.parse_args()
+    if args.full_chain:
+        args.steps = T_CHAIN
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # not under a launcher: start the N rank processes here.  This process has not touched the GPU and never will.
+        from hicdiff_amd.sharding import launch_ranks
+        sys.exit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     if args.workload == "hicedrn64_train":
         return bench_train(args)
     if args.workload == "tiles":
@@ -318,18 +353,7 @@ def main():
     w = dict(WORK[args.workload])
     if args.batch:
         w["B"] = args.batch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    rank, device, world, dist = rank_env(args)
 
     from hicdiff_amd import _lib as L
     from hicdiff_amd.sharding import all_gather_tiles
@@ -346,25 +370,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t = T_CHAIN - 1
-    for _ in range(args.warmup):
-        diff._step_inplace(img, t, cond)
-        t -= 1
+    def run_steps(n, t):
+        """n reverse steps starting at timestep t (wrapping into a new chain below 0); returns the next t."""
+        for _ in range(n):
+            diff._step_inplace(img, t, cond)
+            t = t - 1 if t > 0 else T_CHAIN - 1
+        return t
+
+    # warm-up steps run at the END of a previous chain so that a --steps 1000 region is exactly t = 999 .. 0
+    t = run_steps(args.warmup, (args.warmup - 1) % T_CHAIN)
+    assert t == T_CHAIN - 1
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        diff._step_inplace(img, t, cond)
-        t -= 1
+    t = run_steps(args.steps, t)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
+    sec_per_step = elapsed / args.steps
+    value = (B * world) / (T_CHAIN * sec_per_step)
+
+    # Sustained rate: a whole chain (all ranks, same barriers), with HIP events on the launch stream after 20 steps
+    # and at the end, so the first-20 burst and the steady state of the SAME run can be compared (clock give-back).
+    sustained = None
+    n_sus = int(min(T_CHAIN, args.sustained_budget / max(sec_per_step, 1e-9)))
+    if args.steps >= T_CHAIN:
+        n_sus = 0                                     # the timed region already was a whole chain
+    if n_sus >= 100:
+        burst = min(20, n_sus)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        barrier()
+        s0 = time.perf_counter()
+        ev[0].record()
+        t = run_steps(burst, T_CHAIN - 1)
+        ev[1].record()
+        t = run_steps(n_sus - burst, t)
+        ev[2].record()
+        barrier()
+        sus_s = max_over_ranks(time.perf_counter() - s0, dist, device)
+        sustained = {"steps": n_sus, "ms_per_step": round(sus_s / n_sus * 1e3, 4),
+                     "tiles_per_s": round((B * world) / (T_CHAIN * sus_s / n_sus), 4),
+                     "first_20_ms_per_step": round(ev[0].elapsed_time(ev[1]) / burst, 4),
+                     "rest_ms_per_step": round(ev[1].elapsed_time(ev[2]) / max(n_sus - burst, 1), 4),
+                     "note": "one chain from t=999 timed after the K-step region (rank 0 events; ms_per_step is max over ranks, host clock)"}
+
     # Roofline of the dominant kernel: the same step, launched eagerly with a HIP event pair around every
     # convolution launch on its stream (the timed region above replays a captured hipGraph of the step,
     # inside which per-launch events cannot be recorded).
     prof_steps = max(1, min(args.steps, 5))
     lib.hd_profile_enable(1)
-    for _ in range(prof_steps):
-        diff._step_inplace(img, t, cond)
-        t -= 1
+    t = run_steps(prof_steps, t)
     barrier()
     rows_buf = (L.HdProfileRow * L.HD_PROFILE_MAX_ROWS)()
     n_rows = lib.hd_profile_read(rows_buf, L.HD_PROFILE_MAX_ROWS)
@@ -376,19 +429,13 @@ def main():
             print(f"{r.kernel.decode():58s} {r.launches // prof_steps:4d}/step {ms:7.3f} ms/step {r.flops / r.total_ms / 1e9:7.1f} TFLOP/s-eq "
                   f"{r.bytes / r.total_ms / 1e6:7.0f} GB/s", file=sys.stderr)
 
-    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = el.item()
-    sec_per_step = elapsed / args.steps
-    value = (B * world) / (T_CHAIN * sec_per_step)
-
     # the one collective of the path: gather every rank's finished tiles (rank-ordered)
     gather_ms = None
     if dist is not None:
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        full = all_gather_tiles(img, dist)
+        src = img if dist.get_backend() == "nccl" else img.cpu()
+        full = all_gather_tiles(src, dist)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
         assert full.shape[0] == B * world
@@ -399,6 +446,7 @@ def main():
         split = b"bf16x3" in dom.kernel
         peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
         traffic, traffic_src = recorded_traffic(args.workload, dom.kernel.decode(), B, WORK[args.workload]["B"])
+        whole_flops = w["flop"] * B / sec_per_step / 1e12
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
@@ -411,8 +459,11 @@ def main():
             "all_convs_frac": round(sum(r.flops for r in rows) / max(sum(r.total_ms for r in rows) * 1e-3, 1e-12) / 1e12 / peak, 4),
             "profiled_steps": prof_steps,
             "whole_step": {
-                "flop_frac_of_f32_mfma_peak": round(w["flop"] * B / sec_per_step / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "algorithmic_TFLOPs": round(whole_flops, 1),
+                "frac_of_mfma_roofline": round(whole_flops / peak, 4),
                 "hbm_frac_algorithmic": round((w["act_bytes"] * B + w["w_bytes"]) / sec_per_step / 1e9 / PEAK_HBM_GBS, 4),
+                "note": "SURVEY 8(d) per-tile-step flops / bytes x tiles over the measured step time; MFMA roofline = the peak above, "
+                        "HBM = 8 TB/s (BASELINE target: hbm_frac_algorithmic >= 0.5)",
             },
         }
         out = {
@@ -422,9 +473,13 @@ def main():
             "dtype": "f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
                                    f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
-                       "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}"},
+                       "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
+                       "timed_region": ("one whole chain, t = 999 .. 0" if args.steps == T_CHAIN else
+                                        f"{args.steps} consecutive steps from t = 999 (every step costs the same; see `sustained`)")},
             "roofline": roofline,
         }
+        if sustained is not None:
+            out["sustained"] = sustained
         if gather_ms is not None:
             out["all_gather_ms"] = round(gather_ms, 3)
         if world == 1 and not args.no_cpu_baseline:

@@ -121,14 +121,9 @@ class DiffusionCore(nn.Module):
             "posterior_mean_coef2": (1. - ac_prev) * torch.sqrt(alphas) / (1. - ac),
             "p2_loss_weight": (p2_loss_weight_k + ac / (1 - ac)) ** -p2_loss_weight_gamma,
         }
-        host = {}
         for name, val in table.items():           # the 13 fp32 buffers of src/hicdiff.py:494-522
-            v32 = val.to(torch.float32)
-            self.register_buffer(name, v32)
-            host[name] = v32.clone()
-        # host copies feed the per-step scalars of the C-ABI without a device sync
-        host["sigma"] = (0.5 * host["posterior_log_variance_clipped"]).exp()
-        self.__dict__["_host"] = host
+            self.register_buffer(name, val.to(torch.float32))
+        self.__dict__["_host_cache"] = None       # host copies of the buffers, see _host
 
         self.normalize = (lambda img: img * 2 - 1) if auto_normalize else (lambda img: img)
         self.unnormalize = (lambda t: (t + 1) * 0.5) if auto_normalize else (lambda t: t)
@@ -137,6 +132,25 @@ class DiffusionCore(nn.Module):
         self.noise_source = None     # None: device Philox; or an object with .randn(shape) -> device tensor
         self.seed = 1234             # Philox key for device noise
         self.tile_offset = 0         # global index of this rank's first tile (sharded sampling)
+
+    _HOST_KEYS = ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
+                  "posterior_mean_coef2", "posterior_log_variance_clipped")
+
+    @property
+    def _host(self):
+        """Host copies of the schedule buffers the fused steps take their per-step scalars from (no device sync per step).
+        The reference samples from whatever its registered buffers hold -- a checkpoint (`torch.save(diffusion.state_dict())`,
+        train.py:186) carries all 13 -- so the copies follow the buffers: they are rebuilt whenever a buffer was written
+        (load_state_dict copies in place and bumps `_version`) or replaced (.to(), assign=True)."""
+        bufs = [getattr(self, k) for k in self._HOST_KEYS]
+        sig = tuple((b.data_ptr(), b._version, b.device) for b in bufs)
+        cache = self.__dict__.get("_host_cache")
+        if cache is None or cache[0] != sig:
+            host = {k: b.detach().to("cpu", torch.float32).clone() for k, b in zip(self._HOST_KEYS, bufs)}
+            host["sigma"] = (0.5 * host["posterior_log_variance_clipped"]).exp()
+            cache = (sig, host)
+            self.__dict__["_host_cache"] = cache
+        return cache[1]
 
     # -- small algebra, kept for API parity (device torch ops on gathered scalars) --------------
     def predict_start_from_noise(self, x_t, t, noise):

@@ -96,6 +96,12 @@ class NativeTrainer:
             t, kind = t.detach().to(torch.float32).reshape(-1).contiguous(), L.HD_T_FLOAT32
         else:
             t, kind = t.to(torch.int64).contiguous(), L.HD_T_INT64
+        # Gradient accumulation (several diffusion(x) / backward() pairs before one optimizer.step(), no zero_grad between): the
+        # kernels overwrite the flat gradient buffer, and after the first backward() every p.grad IS a view of that buffer.  Carry
+        # the gradients accumulated so far in a copy; backward() adds them back (as autograd's AccumulateGrad would).
+        if getattr(self, "carry", None) is None and any(
+                p.grad is not None and p.grad.data_ptr() == self.grad_view(i).data_ptr() for i, p in enumerate(self.params)):
+            self.carry = self.grads.clone()
         with torch.cuda.device(self.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             rc = self.lib.hd_train_loss_backward(self.h, _ptr(self.flat), _ptr(self.grads), _ptr(x_start), _ptr(cond), _ptr(t), kind, _ptr(noise),
@@ -126,12 +132,15 @@ class _NativeLoss(torch.autograd.Function):
         one = bool((grad_out == 1).item())
         if not one:
             tr.grads.mul_(grad_out)
+        carry, tr.carry = getattr(tr, "carry", None), None
         for i, p in enumerate(tr.params):
             g = tr.grad_view(i)
             if p.grad is None:
                 p.grad = g                        # a view of the flat gradient buffer: Adam below reads it in place
             elif p.grad.data_ptr() != g.data_ptr():
-                p.grad.add_(g)                    # accumulation over several backward() calls, as autograd would
+                p.grad.add_(g)                    # a .grad tensor of the caller's own: accumulate into it, as autograd would
+            elif carry is not None:
+                g.add_(carry[tr.slots[i][1]:tr.slots[i][1] + g.numel()].view_as(g))    # the live view: add what it held before this forward
         return None, None, None, None
 
 

@@ -913,6 +913,13 @@ int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {
     if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3)) return HD_EINVAL;
+    if (mode != c->precision && !c->graphs.empty()) {
+        // a captured step holds the kernels of the arithmetic it was captured under: drop them with the mode
+        if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
+        if (c->gstream && hipStreamSynchronize(c->gstream) != hipSuccess) return fail(c, HD_EHIP, "stream synchronize failed");
+        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+    }
     c->precision = mode;
     return HD_OK;
 }
@@ -973,6 +980,11 @@ int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, c
     (void)hipStreamSynchronize(st);
     (void)hipFree(pw); (void)hipFree(pf); (void)hipFree(pq); (void)hipFree(ps);
     return rc;
+}
+
+int hd_debug_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_offset, uint32_t step, uint32_t noise_stream, void* stream) {
+    if (!out || B < 1 || (S * S) % 4 || noise_stream > 3) return HD_EINVAL;
+    return launch_randn(out, B, S, seed, tile_offset, step, (hipStream_t)stream, noise_stream);
 }
 
 int hd_debug_capture(hd_ctx* c, int enable) {

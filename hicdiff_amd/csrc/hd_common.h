@@ -159,4 +159,4 @@ int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st)
 int launch_q_sample(const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S,
                     hipStream_t st);
 int launch_loss(const float* pred, const float* target, int l2, float* out, int B, int S, hipStream_t st);
-int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st);
+int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st, uint32_t nstream = 0);

@@ -611,17 +611,17 @@ __device__ __forceinline__ float4 philox_normal4(uint64_t seed, uint32_t quad, u
 }
 
 __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int B, int SS4, uint64_t seed, uint64_t tile_off,
-                                                    uint32_t step) {
+                                                    uint32_t step, uint32_t nstream) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * SS4) return;
     const int b = (int)(i / SS4), q = (int)(i % SS4);
-    reinterpret_cast<float4*>(out)[i] = philox_normal4(seed, q, tile_off + b, step, 0);
+    reinterpret_cast<float4*>(out)[i] = philox_normal4(seed, q, tile_off + b, step, nstream);
 }
 
-int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st) {
+int launch_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, hipStream_t st, uint32_t nstream) {
     const int SS4 = S * S / 4;
     hipLaunchKernelGGL(randn_kernel, dim3((unsigned)(((size_t)B * SS4 + 255) / 256)), dim3(256), 0, st, out, B, SS4, seed, tile_off,
-                       step);
+                       step, nstream);
     return check_launch("randn");
 }
 

@@ -67,3 +67,58 @@ def sample_tiles(diffusion, n_tiles: int, cond: torch.Tensor = None, dist=None) 
         return sample_sharded(run_local, n_tiles, dist)
     finally:
         diffusion.tile_offset = 0
+
+
+def launch_ranks(argv: List[str], n: int, timeout: float = None, extra_env: dict = None) -> int:
+    """Start `n` rank processes of ``argv`` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in the environment, as torch.distributed.run sets them) and wait for them.
+
+    The caller must not have touched the GPU: children are fresh processes (`subprocess.Popen`), nothing is
+    exec'd over an initialised one.  Children inherit stdout / stderr, so the one line rank 0 prints is the
+    caller's output.  Returns 0 when every rank exits 0; if any rank fails (or `timeout` seconds pass) the
+    remaining ranks -- which would otherwise wait in a collective forever -- are terminated and the first
+    non-zero code (124 for a timeout) is returned."""
+    import os
+    import socket
+    import subprocess
+    import time as _time
+    if n < 1:
+        raise ValueError("need at least one rank")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen(list(argv), env=env))
+    t0, rc = _time.monotonic(), 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [c for c in codes if c not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if timeout is not None and _time.monotonic() - t0 > timeout:
+                rc = 124
+                break
+            _time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    return rc

@@ -72,6 +72,12 @@ int hd_debug_linattn_bwd(const float* qkv, const float* dout, int B, int n, int 
 
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);
+
+/* The device Gaussian generator exactly as the fused sampler steps draw from it: Philox4x32-10 keyed by seed, counter = (pixel quad,
+ * global tile index, step, noise_stream), Box-Muller.  hd_randn is noise_stream 0 (the ancestral step's z and DDRM's 'missing' draw,
+ * src/functions/denoising.py:92); 1 = DDRM's 'after' draw (:96), 2 = its 'before' draw (:100).  Tests read the chain's noise with this
+ * and replay it through the CPU oracle. */
+int hd_debug_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_offset, uint32_t step, uint32_t noise_stream, void* stream);
 /* Copy capture `label` (NHWC fp32) to the DEVICE buffer dst (capacity n floats); dims = {B,H,W,C}.
  * Returns HD_EINVAL when the label was not captured. */
 int hd_debug_read(hd_ctx* ctx, const char* label, float* dst, size_t n, int32_t dims[4]);

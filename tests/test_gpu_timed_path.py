@@ -1,0 +1,327 @@
+"""The path `bench.py` times and `inference.py` runs by default -- hipGraph replay of the fused step, step
+scalars read from the device `StepParams` block, noise drawn on the device (Philox4x32-10 + Box-Muller) --
+against the CPU oracle.
+
+The chain's device noise is read back with the test-only `hd_debug_randn` (same key material the step
+kernels use: seed, global tile index, step, noise stream) and replayed through the oracle in the reference's
+call order (src/hicdiff.py:599,607; src/functions/denoising.py:92,96,100), so the comparison covers the
+graph capture, the replayed coefficients and the in-kernel generator at once.
+
+Tolerance (BASELINE.json north_star): 1e-3 relative = max|got - ref| / max|ref| on chains.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from _util import diffusion_class, oracle_hicedrn, oracle_unet, product_hicedrn, product_unet, rel_err, tiles
+
+pytestmark = pytest.mark.gpu
+CHAIN_TOL = 1e-3
+
+
+def _lib():
+    from hicdiff_amd import _lib as L
+    lib = L.load()
+    lib.hd_debug_randn.restype = C.c_int
+    lib.hd_debug_randn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    return lib
+
+
+def device_randn(B, S, seed, tile_offset, step, nstream=0):
+    out = torch.empty((B, 1, S, S), device="cuda", dtype=torch.float32)
+    rc = _lib().hd_debug_randn(C.c_void_p(out.data_ptr()), B, S, seed, tile_offset, step, nstream,
+                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    return out
+
+
+class AncestralDeviceNoise:
+    """oracle-side noise object: the k-th `randn` call returns the device draw the fused chain uses at that
+    point -- x_T is keyed by step = T, the z of reverse step t by step = t (hicdiff_amd/_diffusion.py)."""
+
+    def __init__(self, B, S, T, seed, tile_offset=0):
+        self.B, self.S, self.seed, self.off = B, S, seed, tile_offset
+        self.steps = iter([T] + list(range(T - 1, 0, -1)))
+
+    def randn(self, shape):
+        assert tuple(shape) == (self.B, 1, self.S, self.S)
+        return device_randn(self.B, self.S, self.seed, self.off, next(self.steps)).cpu()
+
+
+class DdrmDeviceNoise:
+    """three draws per executed step k (0-based), noise streams 0 / 1 / 2 = 'missing' / 'after' / 'before'."""
+
+    def __init__(self, B, S, seed):
+        self.B, self.S, self.seed, self.k, self.i = B, S, seed, 0, 0
+
+    def randn(self, shape):
+        n, d = shape
+        stream = self.i
+        self.i += 1
+        k = self.k
+        if self.i == 3:
+            self.i, self.k = 0, self.k + 1
+        if d == 0:
+            return torch.empty((n, 0))
+        return device_randn(self.B, self.S, self.seed, 0, k, stream).cpu().reshape(n, d)
+
+
+@pytest.fixture(params=["bf16x3", "f32"])
+def precision(request, monkeypatch):
+    monkeypatch.setenv("HICDIFF_PRECISION", request.param)
+    return request.param
+
+
+def _set_graphs(model, on):
+    eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
+    assert eng.lib.hd_set_graphs(eng.ctx, 1 if on else 0) == 0
+
+
+# ---------------------------------------------------------------- graph-replayed chains vs oracle
+
+def test_graph_replayed_ancestral_chain_uncond_vs_oracle(precision):
+    B, S, T, seed = 2, 40, 50, 4242
+    net = product_unet("uncond")
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed = seed
+    assert d.noise_source is None                       # -> device Philox, hipGraph replay from the third step on
+    got = d.sample(torch.zeros(B, 1, S, S))
+    from oracle import diffusion as OD
+    ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+    want = ref.p_sample_loop((B, 1, S, S), AncestralDeviceNoise(B, S, T, seed))
+    assert rel_err(want, got) < CHAIN_TOL
+    # the same chain launched eagerly (no graph) is bit-identical: capture / replay changes nothing
+    _set_graphs(net, False)
+    eager = d.sample(torch.zeros(B, 1, S, S))
+    _set_graphs(net, True)
+    assert torch.equal(eager, got)
+    # and a second graph run repeats (the StepParams block is rewritten every step, nothing stale survives a chain)
+    assert torch.equal(d.sample(torch.zeros(B, 1, S, S)), got)
+
+
+def test_graph_replayed_ancestral_chain_cond_vs_oracle(precision):
+    B, S, T, seed = 2, 40, 50, 99
+    net = product_unet("cond")
+    d = diffusion_class("cond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed = seed
+    lq = tiles(17, B, S)
+    got = d.super_resolution(lq.cuda())
+    from oracle import diffusion as OD
+    ref = OD.DiffusionRef(oracle_unet("cond"), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind="cond")
+    want = ref.p_sample_loop(lq, AncestralDeviceNoise(B, S, T, seed))
+    assert rel_err(want, got) < CHAIN_TOL
+    _set_graphs(net, False)
+    eager = d.super_resolution(lq.cuda())
+    _set_graphs(net, True)
+    assert torch.equal(eager, got)
+
+
+def test_graph_replayed_chain_with_tile_offset_vs_oracle(precision):
+    """A shard's chain (tile_offset != 0) draws the noise of its GLOBAL tiles -- also on the replayed path."""
+    B, S, T, seed, off = 3, 16, 50, 7, 5
+    net = product_unet("uncond", 16, (1, 2))
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed, d.tile_offset = seed, off
+    got = d.sample(torch.zeros(B, 1, S, S))
+    from oracle import diffusion as OD
+    ref = OD.DiffusionRef(oracle_unet("uncond", 16, (1, 2)), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+    want = ref.p_sample_loop((B, 1, S, S), AncestralDeviceNoise(B, S, T, seed, off))
+    assert rel_err(want, got) < CHAIN_TOL
+
+
+@pytest.mark.parametrize("net_kind", ["unet", "hicedrn3"])
+@pytest.mark.parametrize("sigma_0", [0.1, 1.0])
+def test_graph_replayed_ddrm_chain_vs_oracle(net_kind, sigma_0, precision):
+    """inference.py -u 1 as it runs by default: DDRM 'deno', 50 of 1000 steps, device noise, graph replay.
+    sigma_0 = 0.1 crosses from the 'before' to the 'after' branch inside the chain, 1.0 stays 'after' longer."""
+    from hicdiff_amd.functions.H_func import MakeFunc
+    from hicdiff_amd.functions.denoising import efficient_generalized_steps
+    from oracle import ddrm as ODD
+    B, S, seed = 2, 40, 31337
+    m = product_unet("uncond") if net_kind == "unet" else product_hicedrn("uncond", 3)
+    ref_model = oracle_unet("uncond") if net_kind == "unet" else oracle_hicedrn("uncond", 3)
+    betas = ODD.ddrm_betas("linear", 1000)
+    hq = tiles(5, B, S)
+    y0 = (hq + sigma_0 * torch.randn(hq.shape, generator=torch.Generator().manual_seed(6))).clamp(-1, 1)
+    x = device_randn(B, S, seed, 0, 1000)          # any start state; the same tensor goes to both sides
+    H = MakeFunc("deno", 1, S, device="cuda")
+    seq = range(0, 1000, 20)
+    xs, x0s = efficient_generalized_steps(x.clone(), seq, m, betas.cuda(), H, y0.cuda(), sigma_0, etaB=1.0, etaA=0.85, etaC=0.85,
+                                          noise=None, seed=seed)
+    want, want_x0 = ODD.ddrm_denoise(x.cpu(), list(seq), ref_model, betas, y0, sigma_0,
+                                     noise=DdrmDeviceNoise(B, S, seed))
+    assert rel_err(want, xs[-1]) < CHAIN_TOL
+    assert rel_err(want_x0, x0s[-1]) < CHAIN_TOL
+    _set_graphs(m, False)
+    xs2, _ = efficient_generalized_steps(x.clone(), seq, m, betas.cuda(), H, y0.cuda(), sigma_0, etaB=1.0, etaA=0.85, etaC=0.85,
+                                         noise=None, seed=seed)
+    _set_graphs(m, True)
+    assert torch.equal(xs2[-1], xs[-1])
+
+
+def test_precision_switch_drops_captured_graphs():
+    """hd_set_precision between two chains on the same tensors: the second chain must run the new arithmetic
+    (graphs are keyed by tensor addresses, which the caching allocator hands back)."""
+    from hicdiff_amd import _lib as L
+    B, S, T = 2, 16, 20
+    net = product_unet("uncond", 16, (1, 2))
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    eng = net.engine(torch.device("cuda", torch.cuda.current_device()))
+    eng.set_precision(L.HD_PRECISION_BF16X3)
+    img = d._initial_noise((B, 1, S, S), torch.device("cuda"))
+    keep = img.clone()
+
+    def chain():
+        img.copy_(keep)
+        for t in reversed(range(T)):
+            d._step_inplace(img, t, None)
+        return img.clone()
+
+    fast = chain()
+    eng.set_precision(L.HD_PRECISION_F32)
+    exact = chain()                         # same `img` address: a stale graph would replay the bf16x3 kernels
+    _set_graphs(net, False)
+    exact_eager = chain()
+    _set_graphs(net, True)
+    eng.set_precision(L.HD_PRECISION_BF16X3)
+    assert torch.equal(exact, exact_eager)
+    assert not torch.equal(exact, fast)
+    assert rel_err(exact, fast) < CHAIN_TOL
+
+
+# ---------------------------------------------------------------- the device generator itself
+
+def test_device_gaussian_moments_and_ks():
+    """10^7 draws of the Philox4x32-10 + Box-Muller generator (fast-math log / sincos): moments and a
+    Kolmogorov-Smirnov bound against N(0,1).  Standard errors at n = 1e7: mean 3.2e-4, variance 4.5e-4,
+    skewness 7.7e-4, excess kurtosis 1.5e-3; bounds are 5 sigma."""
+    from scipy import stats
+    n_tiles, S = 2442, 64                       # 2442 * 4096 = 10 002 432 draws
+    z = device_randn(n_tiles, S, 1234, 0, 17).double().flatten()
+    n = z.numel()
+    mean, var = z.mean().item(), z.var().item()
+    zc = (z - mean) / var ** 0.5
+    skew, kurt = (zc ** 3).mean().item(), (zc ** 4).mean().item() - 3.0
+    assert abs(mean) < 5 * n ** -0.5, mean
+    assert abs(var - 1) < 5 * (2 / n) ** 0.5, var
+    assert abs(skew) < 5 * (6 / n) ** 0.5, skew
+    assert abs(kurt) < 5 * (24 / n) ** 0.5, kurt
+    zs = z.cpu().numpy()
+    ks = stats.kstest(zs, "norm")
+    assert ks.statistic < 1.63 / n ** 0.5, ks              # 1 % critical value of the KS statistic
+    # tails: P(|z| > 4) = 6.33e-5 -> 633 expected in 1e7, sd 25; the largest of 1e7 normals sits near 5.3
+    tail = int((np.abs(zs) > 4).sum())
+    assert abs(tail - 6.334e-5 * n) < 6 * (6.334e-5 * n) ** 0.5, tail
+    assert 4.6 < np.abs(zs).max() < 6.5, np.abs(zs).max()
+    # Box-Muller pairs (cos, sin of one angle / two radii per counter) are uncorrelated
+    q = z.reshape(-1, 4)
+    for a in range(4):
+        for b in range(a + 1, 4):
+            r = (q[:, a] * q[:, b]).mean().item()
+            assert abs(r) < 5 * (n / 4) ** -0.5, (a, b, r)
+
+
+def test_device_gaussian_streams_are_distinct():
+    """Different (tile, step, noise stream, seed) give different, uncorrelated fields; the same key repeats."""
+    S = 64
+    base = device_randn(4, S, 5, 0, 9, 0)
+    assert torch.equal(base, device_randn(4, S, 5, 0, 9, 0))
+    others = {
+        "tile": device_randn(4, S, 5, 4, 9, 0), "step": device_randn(4, S, 5, 0, 10, 0), "stream1": device_randn(4, S, 5, 0, 9, 1),
+        "stream2": device_randn(4, S, 5, 0, 9, 2), "seed": device_randn(4, S, 6, 0, 9, 0), "seed_hi": device_randn(4, S, 5 + (1 << 32), 0, 9, 0),
+    }
+    n = base.numel()
+    for name, o in others.items():
+        assert not torch.equal(o, base), name
+        r = (o.double() * base.double()).mean().item()
+        assert abs(r) < 5 * n ** -0.5, (name, r)
+    # tile_offset is a plain shift of the global tile index
+    assert torch.equal(device_randn(4, S, 5, 2, 9, 0)[:2], base[2:])
+    # tiles inside one call differ from each other
+    assert not torch.equal(base[0], base[1])
+
+
+# ---------------------------------------------------------------- BASELINE batch size: B = 256, S = 64
+
+@pytest.mark.parametrize("kind", ["uncond", "cond"])
+def test_eps_at_bench_batch_size_vs_oracle(kind, precision):
+    """BASELINE configs[1..3]'s batch: one 256-tile, 64x64 forward; four sampled tiles of it against the
+    oracle (per-forward bound of tests/test_gpu_parity.py) and slices of the batch bit for bit."""
+    B, S = 256, 64
+    m, ref = product_unet(kind), oracle_unet(kind)
+    x = tiles(256, B, S)
+    cond = tiles(257, B, S) if kind == "cond" else None
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(8))
+    xd, td, cd = x.cuda(), t.cuda(), None if cond is None else cond.cuda()
+    full = m(xd, td, cd)
+    pick = torch.tensor([0, 101, 200, 255])
+    want = ref(x[pick], t[pick], None if cond is None else cond[pick])
+    assert rel_err(want, full[pick.cuda()]) < 1e-4
+    assert torch.equal(full, m(xd, td, cd))
+    part = m(xd[96:160], td[96:160], None if cd is None else cd[96:160])
+    assert torch.equal(full[96:160], part)
+
+
+def test_hicedrn32_eps_at_64_vs_oracle(precision):
+    """BASELINE configs[3]'s network at its tile size: all 32 blocks at 64x64 (the golden fixture pins 32 blocks at
+    40x40 and 3 blocks at 64x64)."""
+    m, ref = product_hicedrn("uncond", 32), oracle_hicedrn("uncond", 32)
+    x = tiles(11, 2, 64)
+    t = torch.tensor([3, 950])
+    assert rel_err(ref(x, t, None), m(x.cuda(), t.cuda())) < 1e-4
+
+
+# ---------------------------------------------------------------- full-length chain: drift over 1000 steps
+
+_DRIFT = {}
+
+
+def _oracle_1000(B, S, T, seed):
+    key = (B, S, T, seed)
+    if key not in _DRIFT:
+        from oracle import diffusion as OD
+        ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+        _DRIFT[key] = ref.p_sample_loop((B, 1, S, S), AncestralDeviceNoise(B, S, T, seed), keep_every=100)
+    return _DRIFT[key]
+
+
+def test_full_length_chain_drift_vs_oracle(precision, capsys):
+    """BASELINE's headline is a 1000-step chain: the full-size UNet, 2 tiles of 40x40, T = 1000 with device noise on
+    the graph-replayed path against the CPU oracle over the same noise.  Prints the drift every 100 steps (DESIGN.md
+    section 2 quotes it)."""
+    B, S, T, seed = 2, 40, 1000, 2026
+    net = product_unet("uncond")
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed = seed
+    stack = d.sample(torch.zeros(B, 1, S, S), return_all_timesteps=True)      # (B, T+1, 1, S, S); index T - t = state after step t
+    want, kept = _oracle_1000(B, S, T, seed)
+    drift = {t: rel_err(kept[t], stack[:, T - t]) for t in sorted(kept, reverse=True)}
+    with capsys.disabled():
+        print(f"\n[drift {precision}] " + " ".join(f"t={t}:{e:.2e}" for t, e in drift.items()))
+    assert rel_err(want, stack[:, T]) < CHAIN_TOL
+    assert max(drift.values()) < CHAIN_TOL
+
+
+# ---------------------------------------------------------------- bench.py --gpus N as the driver runs it
+
+def test_bench_two_ranks_self_launched_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: bench.py starts both ranks itself (gloo rendezvous and both ranks on
+    GPU 0 here, because the test box has one card; RCCL over two cards is the same code with the default backend)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HICDIFF_BENCH_BACKEND="gloo", HICDIFF_DEVICE="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--workload", "unet40",
+                          "--batch", "4", "--no-cpu-baseline", "--sustained-budget", "0"], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0 and "all_gather_ms" in line
+    assert abs(line["value"] - 2 * 4 / (1000 * line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]

@@ -203,6 +203,39 @@ def test_train_ragged_batch_keeps_adam_state():
     assert dist(keep) < 0.25 * dist(reset), (dist(keep), dist(reset))
 
 
+def test_train_gradient_accumulation_over_micro_batches():
+    """Two diffusion(x) / backward() pairs with no zero_grad between leave the SUM of both micro-batches' gradients in .grad
+    (torch's AccumulateGrad semantics), although the kernels overwrite the flat gradient buffer the .grad views alias."""
+    d = _diffusion("cond", 1, 16)
+    d.train()
+    draws = []
+    for k in range(2):
+        gen = torch.Generator().manual_seed(40 + k)
+        draws.append((tiles(80 + k, 3, 16).cuda(), tiles(90 + k, 3, 16).cuda(), torch.randint(0, 1000, (3,), generator=gen).cuda(),
+                      torch.randn((3, 1, 16, 16), generator=gen).cuda()))
+    singles = []
+    for lq, x0, t, eps in draws:
+        d.p_losses([lq, x0], t, eps).backward()
+        singles.append({n: p.grad.clone() for n, p in d.model.named_parameters()})
+        for p in d.parameters():
+            p.grad = None
+    for lq, x0, t, eps in draws:
+        d.p_losses([lq, x0], t, eps).backward()               # no zero_grad in between
+    for n, p in d.model.named_parameters():
+        want = singles[0][n] + singles[1][n]
+        assert torch.allclose(p.grad, want, rtol=0, atol=1e-6 * float(want.abs().max()) + 1e-12), n
+    # a third micro-batch keeps accumulating, and zero_grad starts over
+    lq, x0, t, eps = draws[0]
+    d.p_losses([lq, x0], t, eps).backward()
+    n0, p0 = next(iter(d.model.named_parameters()))
+    want = 2 * singles[0][n0] + singles[1][n0]
+    assert torch.allclose(p0.grad, want, rtol=0, atol=2e-6 * float(want.abs().max()))
+    for p in d.parameters():
+        p.grad = None
+    d.p_losses([lq, x0], t, eps).backward()
+    assert torch.equal(p0.grad, singles[0][n0])
+
+
 def test_train_errors():
     from hicdiff_amd.optim import Adam
     from _util import product_unet
@@ -235,7 +268,7 @@ def test_train_cli_trains_and_writes_reference_checkpoints(tmp_path, capsys):
     assert [l["Epoch"] for l in lines] == [1, 2, 3, 4]
     assert lines[-1]["train/loss"] < 0.8 * lines[0]["train/loss"] and best == min(l["valid/loss"] for l in lines)
     names = sorted(p.name for p in tmp_path.iterdir())
-    assert names == ["bestg_40000_c64_s16_Human1_HiCedrn_cond_l2_lin.pytorch", "finalg_40000_c64_s16_Human1_HiCedrn_cond_l2_lin.pytorch"]
+    assert names == ["bestg_40000_c16_s16_Human1_HiCedrn_cond_l2_lin.pytorch", "finalg_40000_c16_s16_Human1_HiCedrn_cond_l2_lin.pytorch"]
     from hicdiff_amd.hicdiff_condition import GaussianDiffusion
     from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
     d = GaussianDiffusion(hicedrn_Diff(number_resnet=2, self_condition=True), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear")
@@ -252,8 +285,8 @@ def test_train_two_ranks_stay_in_sync(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HICDIFF_DEVICE="0", HICDIFF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29731",
-           os.path.join(root, "train.py"), "-u", "", "-b", "4", "-e", "2", "--resnet-blocks", "1", "--tile", "16", "--tiles-per-epoch", "16",
-           "--lr", "5e-4", "--weights-dir", str(tmp_path), "--print-checksum"]
+           os.path.join(root, "train.py"), "-u", "", "-b", "4", "-e", "2", "--resnet-blocks", "1", "--tile", "16", "--tiles-per-epoch", "18",
+           "--lr", "5e-4", "--weights-dir", str(tmp_path), "--print-checksum"]        # 18 tiles = 4 full batches + a ragged fifth: an ODD batch count over 2 ranks
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     sums = {}
@@ -263,7 +296,7 @@ def test_train_two_ranks_stay_in_sync(tmp_path):
             sums[j["rank"]] = (j["param_sum"], j["param_abs_sum"])
     assert set(sums) == {0, 1} and sums[0] == sums[1]
     single = subprocess.run([sys.executable, os.path.join(root, "train.py"), "-u", "", "-b", "4", "-e", "2", "--resnet-blocks", "1", "--tile", "16",
-                             "--tiles-per-epoch", "16", "--lr", "5e-4", "--weights-dir", str(tmp_path / "one"), "--print-checksum"],
+                             "--tiles-per-epoch", "18", "--lr", "5e-4", "--weights-dir", str(tmp_path / "one"), "--print-checksum"],
                             env=env, capture_output=True, text=True, timeout=600)
     assert single.returncode == 0, single.stderr[-2000:]
     one = [json.loads(l) for l in single.stdout.splitlines() if "param_sum" in l][0]
@@ -650,4 +683,4 @@ def test_train_cli_unet(tmp_path, capsys):
     train.main(["-u", "", "-b", "4", "-e", "3", "--arch", "unet", "--tile", "32", "--tiles-per-epoch", "16", "--lr", "3e-4", "--weights-dir", str(tmp_path)])
     lines = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
     assert len(lines) == 3 and lines[-1]["train/loss"] < 0.9 * lines[0]["train/loss"], lines
-    assert sorted(p.name for p in tmp_path.iterdir()) == ["bestg_40000_c64_s32_Human1_Unet_cond_l2_lin.pytorch", "finalg_40000_c64_s32_Human1_Unet_cond_l2_lin.pytorch"]
+    assert sorted(p.name for p in tmp_path.iterdir()) == ["bestg_40000_c32_s32_Human1_unet_cond_l2_lin.pytorch", "finalg_40000_c32_s32_Human1_unet_cond_l2_lin.pytorch"]

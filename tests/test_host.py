@@ -7,6 +7,7 @@ import re
 import socket
 import subprocess
 import sys
+import time
 
 import pytest
 import torch
@@ -247,8 +248,87 @@ def test_cli_flags_match_the_reference():
     assert (a.unspervised, a.batch_size, a.epoch, a.celline, a.celln, a.sigma) == (True, 64, 400, "Human", 1, 1)
     assert inference.create_parser().parse_args(["-u", "0"]).unspervised is True       # type=bool: any non-empty string
     assert inference.create_parser().parse_args(["-u", ""]).unspervised is False
+    d = train.create_parser().parse_args([])
+    assert (d.unspervised, d.batch_size, d.epoch, d.celline, d.celln, d.sigma) == (True, 64, 400, "Human", 1, 1)     # train.py:30-39
+    assert train.create_parser().parse_args(["-u", ""]).unspervised is False
     t = train.create_parser().parse_args(["-b", "32", "-e", "3", "-l", "Dros", "-n", "2"])
     assert (t.batch_size, t.epoch, t.celline, t.celln) == (32, 3, "Dros", 2)
     assert train.create_parser().parse_args(["--arch", "unet", "--precision", "bf16"]).precision == "bf16"   # both networks train natively
     lq, hq = inference.synthetic_tiles(3, 16, 0.1, 7)
     assert lq.shape == hq.shape == (3, 1, 16, 16) and torch.equal(hq, hq.transpose(-1, -2)) and lq.abs().max() <= 1
+
+
+_LAUNCH_WORKER = r"""
+import json, os, sys, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+if len(sys.argv) > 1 and sys.argv[1] == "fail" and rank == 1:
+    sys.exit(7)                                   # rank 0 would now wait in the collective forever
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "max": t.item()}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_launch_ranks_starts_n_processes_and_reaps_them_on_failure(tmp_path):
+    """What `python bench.py --gpus N` does when it is not under torchrun (hicdiff_amd/sharding.py::launch_ranks):
+    N fresh rank processes with the torchrun environment, rank 0's line on the caller's stdout, non-zero exit and no
+    stragglers when a rank dies."""
+    script = tmp_path / "w.py"
+    script.write_text(_LAUNCH_WORKER)
+    code = ("import sys; sys.path.insert(0, %r); from hicdiff_amd.sharding import launch_ranks; "
+            "sys.exit(launch_ranks([sys.executable, %r] + sys.argv[1:], 2, timeout=100))" % (ROOT, str(script)))
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=150)
+    assert ok.returncode == 0, ok.stderr.decode()
+    assert json.loads(ok.stdout.decode().strip().splitlines()[-1]) == {"n_gpus": 2, "max": 2.0}
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, "-c", code, "fail"], capture_output=True, timeout=150)
+    assert bad.returncode == 7 and time.time() - t0 < 60       # the surviving rank was terminated, not waited for
+
+
+def test_bench_self_launch_happens_before_any_gpu_use():
+    """bench.py --gpus N without RANK must hand over to launch_ranks before importing the HIP library or calling torch.cuda."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    spawn = main.index("launch_ranks(")
+    for needle in ("rank_env(args)", "L.load()", "torch.cuda", "bench_train(args)", "bench_tiles(args)"):
+        assert main.index(needle) > spawn, needle
+
+
+def test_fused_step_coefficients_follow_a_loaded_checkpoint():
+    """A reference checkpoint carries the 13 schedule buffers and the reference samples from them (src/hicdiff.py:494-522):
+    loading a 'linear' checkpoint into an object constructed with 'sigmoid' must switch the fused sampler's per-step scalars
+    too, not only q_sample's buffers."""
+    from hicdiff_amd.hicdiff import GaussianDiffusion, Unet
+    net = Unet(16, dim_mults=(1, 2))
+    lin = GaussianDiffusion(net, image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear")
+    sig = GaussianDiffusion(net, image_size=16, timesteps=1000, loss_type="l2", beta_schedule="sigmoid")
+    fields = ("sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2", "sigma")
+    before = [getattr(sig._coef(500), f) for f in fields]
+    want = [getattr(lin._coef(500), f) for f in fields]
+    assert before != want
+    sig.load_state_dict(lin.state_dict())
+    assert [getattr(sig._coef(500), f) for f in fields] == want
+    assert torch.equal(sig._host["alphas_cumprod"], lin.alphas_cumprod)          # DDIM reads this one
+    # and the table is only re-read when a buffer changed
+    assert sig._host is sig._host
+
+
+def test_every_rank_runs_the_same_number_of_optimizer_steps():
+    """train.py's batch plan: each training step ends in a collective, so ranks must take equally many batches for any tile
+    count (the reference's DataLoader keeps the ragged tail; here it is filled up so the trainer's batch size never changes)."""
+    import train
+    for n, bs, world in ((256, 64, 8), (1000, 64, 8), (65, 64, 2), (7, 64, 3), (640, 64, 3), (64, 64, 1)):
+        plans = [train.batch_plan(n, bs, r, world, True) for r in range(world)]
+        assert len({len(p) for p in plans}) == 1 and len(plans[0]) >= 1, (n, bs, world)
+        assert all(len(b) == bs for p in plans for b in p)
+        seen = {i for p in plans for b in p for i in b}
+        assert seen == set(range(n))                                           # every tile is trained on
+        val = [train.batch_plan(n, bs, r, world, False) for r in range(world)]
+        flat = sorted(i for p in val for b in p for i in b)
+        assert flat == list(range(n))                                          # validation: each tile exactly once, ragged tail kept
+    assert train.batch_plan(0, 64, 0, 2, True) == []

@@ -32,7 +32,7 @@ def create_parser():
     p.add_argument("-e", "--epoch", type=int, default=400)
     p.add_argument("-l", "--celline", type=str, default="Human")
     p.add_argument("-n", "--celln", type=int, default=1)
-    p.add_argument("-s", "--sigma", type=float, default=0.1)
+    p.add_argument("-s", "--sigma", type=float, default=1)               # train.py:38
     p.add_argument("--arch", choices=["hicedrn", "unet"], default="hicedrn")
     p.add_argument("--resnet-blocks", type=int, default=32)
     p.add_argument("--tile", type=int, default=64)
@@ -50,25 +50,57 @@ def create_parser():
     return p
 
 
-def _batches(args, epoch, split, rank, world, device):
-    """Yield (data, target) batches of exactly batch_size tiles; ranks take disjoint batches."""
-    bs = args.batch_size
-    if args.data_root:
+class _Tiles:
+    """The (low-coverage, target) tiles of both splits, loaded ONCE (the reference builds its DataLoaders once, train.py:75-84).
+    Under torchrun rank 0 alone runs `prepare_data` (it may write the Splits/ files); the others wait at a barrier."""
+
+    def __init__(self, args, rank, dist):
+        self.args, self.sets = args, {}
+        if not args.data_root:
+            return
         from hicdiff_amd.processdata import GSE130711Module, GSE131811Module
         cls = GSE130711Module if args.celline == "Human" else GSE131811Module
-        dm = cls(batch_size=bs, res=40000, piece_size=args.tile, cell_line=args.celline, cell_No=args.celln, sigma_0=args.sigma, root=args.data_root)
-        dm.prepare_data()
+        dm = cls(batch_size=args.batch_size, res=40000, piece_size=args.tile, cell_line=args.celline, cell_No=args.celln, sigma_0=args.sigma,
+                 root=args.data_root)
+        if rank == 0:
+            dm.prepare_data()
+        if dist is not None:
+            dist.barrier()
         dm.setup("fit")
-        ds = dm.train_set if split == "train" else dm.val_set
-        g = torch.Generator().manual_seed(args.seed + epoch)
-        order = torch.randperm(len(ds), generator=g) if split == "train" else torch.arange(len(ds))
-        lq, hq = ds.data[order], ds.target[order]
-    else:
-        from inference import synthetic_tiles
-        lq, hq = synthetic_tiles(args.tiles_per_epoch, args.tile, args.sigma, args.seed + 2 * epoch + (split != "train"))
-    nb = lq.shape[0] // bs                                               # the native trainer is sized for full batches; the ragged tail is dropped
-    for i in range(rank, nb, world):
-        yield lq[i * bs:(i + 1) * bs].to(device), hq[i * bs:(i + 1) * bs].to(device)
+        self.sets = {"train": (dm.train_set.data, dm.train_set.target), "valid": (dm.val_set.data, dm.val_set.target)}
+
+    def split(self, epoch, split):
+        args = self.args
+        if not self.sets:
+            from inference import synthetic_tiles
+            return synthetic_tiles(args.tiles_per_epoch, args.tile, args.sigma, args.seed + 2 * epoch + (split != "train"))
+        lq, hq = self.sets[split]
+        if split == "train":                                             # DataLoader(shuffle=True): a new order every epoch, the same on every rank
+            order = torch.randperm(lq.shape[0], generator=torch.Generator().manual_seed(args.seed + epoch))
+            return lq[order], hq[order]
+        return lq, hq
+
+
+def batch_plan(n, bs, rank, world, train):
+    """Index lists of this rank's batches.  The reference's DataLoader has no drop_last (PrepareData_linear_sing.py:336-339): every tile
+    is seen once per epoch.  Training: every batch has exactly `bs` tiles (the native trainer is sized for it) -- the ragged tail is filled
+    up with tiles from the head of the epoch's order -- and EVERY RANK GETS THE SAME NUMBER OF BATCHES (each optimiser step is a collective:
+    a rank with fewer steps would leave the others waiting in the all-reduce), the last round being filled by wrapping around.
+    Validation (no collective inside the loop, no fixed batch size): plain round-robin, ragged tail kept."""
+    if n <= 0:
+        return []
+    nb = -(-n // bs)
+    if not train:
+        return [list(range(i * bs, min((i + 1) * bs, n))) for i in range(rank, nb, world)]
+    rounds = -(-nb // world)
+    return [[j % n for j in range((i % nb) * bs, (i % nb) * bs + bs)] for i in range(rank, rounds * world, world)]
+
+
+def _batches(tiles, epoch, split, rank, world, device):
+    lq, hq = tiles.split(epoch, split)
+    for idx in batch_plan(lq.shape[0], tiles.args.batch_size, rank, world, split == "train"):
+        idx = torch.as_tensor(idx)
+        yield lq[idx].to(device), hq[idx].to(device)
 
 
 def main(argv=None):
@@ -106,8 +138,11 @@ def main(argv=None):
     torch.manual_seed(args.seed + 1000 * (rank + 1))                     # timesteps and noise differ per rank
     best = float("inf")
     os.makedirs(args.weights_dir, exist_ok=True)
-    tag = "HiCedrn" if args.arch == "hicedrn" else "Unet"
-    stem = f"g_40000_c64_s{args.tile}_{args.celline}{args.celln}_{tag}{'_cond' if conditional else ''}_l2_lin.pytorch"
+    # train.py:185,189 names every checkpoint `..._HiCedrn_cond_l2_lin.pytorch` with c{chunk}_s{chunk}, whatever -u says (inference.py loads
+    # exactly that name); the UNet stems are those of pretrain/train_unet_Diff_cond.py:145,149
+    tag = "HiCedrn_cond_l2_lin" if args.arch == "hicedrn" else "unet_cond_l2_lin"
+    stem = f"g_40000_c{args.tile}_s{args.tile}_{args.celline}{args.celln}_{tag}.pytorch"
+    tiles = _Tiles(args, rank, dist)
 
     def mean_over_ranks(total, count):
         if dist is not None:
@@ -119,7 +154,7 @@ def main(argv=None):
     for epoch in range(1, args.epoch + 1):
         diffusion.train()
         tot, n = 0.0, 0
-        for data, target in _batches(args, epoch, "train", rank, world, device):
+        for data, target in _batches(tiles, epoch, "train", rank, world, device):
             x = [data, target] if conditional else target               # train.py:127-130
             if optimise:
                 loss = diffusion(x)
@@ -135,7 +170,7 @@ def main(argv=None):
         diffusion.eval()
         tot, n = 0.0, 0
         with torch.no_grad():
-            for data, target in _batches(args, epoch, "valid", rank, world, device):
+            for data, target in _batches(tiles, epoch, "valid", rank, world, device):
                 tot += float(diffusion([data, target] if conditional else target)) * data.shape[0]
                 n += data.shape[0]
         valid_loss = mean_over_ranks(tot, n)
