@@ -11,7 +11,7 @@ struct ConvKArgs {
     const float* in0; const float* in1;
     int C0, C1, Cin;
     int B, H, W, IH, IW, stride, pad, upsample, KH, KW;
-    const float* w; const unsigned short* wsplit; const float* bias;
+    const float* w; const unsigned short* wsplit; const unsigned short* wino; const float* bias;
     int Cout, CoutPad;
     int TB, TH, TW, LH, LW, npx, tiles_x, tiles_y, ntiles_n;
     int xs_stride;               // bf16x3 kernel: bytes between its two activation windows in LDS (0: single window)
@@ -368,6 +368,7 @@ struct ConvLaunch {
 };
 int launch_conv_f32(ConvLaunch& L, hipStream_t st);
 int launch_conv_bf16x3(ConvLaunch& L, hipStream_t st);
+int launch_conv_winograd(ConvLaunch& L, hipStream_t st);   // 16 x 16 pixel blocks of one sample: tiles_y = H / 16, tiles_x = W / 16, ntiles_n = CoutPad / 64
 int conv_bf16x3_max_items(int cfg, int ck, bool taps9, bool layernorm);
 void conv_prof_begin(const ConvLaunch& L, const char* name, hipStream_t st);   // name: the instantiation as rocprofv3 prints it (string literal)
 void conv_prof_end(hipStream_t st);

@@ -180,9 +180,25 @@ static bool gn_in_epilogue(const ConvPlan& pl) {
 // (grid.y) write raw partial sums that splitk_reduce_kernel adds in a fixed order (+ bias).  The rule looks at the map
 // size only, never at the batch, so results do not depend on how many tiles are sampled together.  8x8 maps are left alone:
 // at 256 tiles they already give 512 workgroups (the headline workload), and one rule has to serve every batch.
+// Winograd F(2x2,3x3) (conv_winograd.hip) can take the stride-1 3x3 convolutions whose feature map is made of 16 x 16 pixel
+// blocks (64x64, 32x32, 16x16 maps): 2.25 x fewer MFMAs.  By the layer's shape only -- never by the batch.
+// OFF by default: as measured in round 2 the kernel is correct but not faster than the implicit-GEMM kernel;
+// HICDIFF_WINOGRAD=1 or hd_debug_winograd(1) routes the eligible layers through it.
+static int g_wino_mode = -1;           // -1: environment, 0: off, 1: on
+void conv_set_winograd(int mode) { g_wino_mode = mode; }
+bool conv_uses_winograd(const ConvArgs& a) {
+    static const bool env_on = getenv("HICDIFF_WINOGRAD") && atoi(getenv("HICDIFF_WINOGRAD")) != 0;
+    const bool on = g_wino_mode < 0 ? env_on : g_wino_mode != 0;
+    if (!on || a.precision != HD_PREC_BF16X3 || !a.cw.wino || a.cw.KH != 3 || a.cw.KW != 3 || a.stride != 1 || a.pad != 1) return false;
+    if (a.H % 16 || a.W % 16 || a.C0 % 16 || a.C1 % 16 || a.cw.CoutPad % 64 || a.cw.Cout % 4 || a.w_bstride || a.plain_bf16) return false;
+    if (a.in_mode != IN_NONE && a.in_mode != IN_AFFINE_SILU) return false;
+    if (a.ep & ~(EP_FILM_SILU | EP_ADD_SILU | EP_RES)) return false;
+    return a.upsample ? (a.IH * 2 == a.H && a.IW * 2 == a.W) : (a.IH == a.H && a.IW == a.W);
+}
+
 int conv_splitk(const ConvArgs& a) {
     static const int forced = getenv("HICDIFF_SPLITK") ? atoi(getenv("HICDIFF_SPLITK")) : -1;
-    if (forced == 0) return 1;
+    if (forced == 0 || conv_uses_winograd(a)) return 1;
     if (a.precision != HD_PREC_BF16X3 || !a.cw.wsplit || a.cw.KH != 3 || a.cw.KW != 3 || a.stride != 1 || a.upsample || a.ep != 0 || a.w_bstride ||
         (a.in_mode != IN_NONE && a.in_mode != IN_AFFINE_SILU))
         return 1;
@@ -220,6 +236,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 int conv_gn_slots(const ConvArgs& a) {
+    if (conv_uses_winograd(a)) return (a.H / 16) * (a.W / 16);   // one slot per 16 x 16 block
     if (conv_splitk(a) > 1) return 1;             // one slot per sample, written by the split-K reduce (which sees the finished output)
     const ConvPlan pl = plan_conv(a);
     if (!gn_in_epilogue(pl)) return 0;
@@ -232,7 +249,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.in0 = a.in0; k.in1 = a.in1; k.C0 = a.C0; k.C1 = a.C1; k.Cin = a.C0 + a.C1;
     k.B = a.B; k.H = a.H; k.W = a.W; k.IH = a.IH; k.IW = a.IW;
     k.stride = a.stride; k.pad = a.pad; k.upsample = a.upsample; k.KH = a.cw.KH; k.KW = a.cw.KW;
-    k.w = a.cw.w; k.wsplit = a.cw.wsplit; k.bias = a.cw.bias; k.Cout = a.cw.Cout; k.CoutPad = a.cw.CoutPad;
+    k.w = a.cw.w; k.wsplit = a.cw.wsplit; k.wino = a.cw.wino; k.bias = a.cw.bias; k.Cout = a.cw.Cout; k.CoutPad = a.cw.CoutPad;
     k.in_mode = a.in_mode; k.inA = a.inA; k.inB = a.inB; k.inE = a.inE; k.in_bstride = a.in_bstride;
     k.ln_stats = a.ln_stats; k.ln_g = a.ln_g;
     k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
@@ -245,6 +262,15 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ablate = ablate;
     static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;
     k.stagger = stagger;
+    if (conv_uses_winograd(a)) {
+        if (k.Cin != a.cw.Cin) { hd_set_error("conv: channel counts do not match the packed weight"); return -1; }
+        k.tiles_y = a.H / 16; k.tiles_x = a.W / 16; k.ntiles_n = k.CoutPad / 64;
+        k.TB = 1; k.TH = k.TW = 16; k.LH = k.LW = 18; k.npx = 324;
+        k.gn_part = a.gn_part; k.gn_slots = a.gn_part ? k.tiles_y * k.tiles_x : 0;
+        if (gn_slots_out) *gn_slots_out = k.gn_slots;
+        L.ck = 16; L.cfg = 4;
+        return launch_conv_winograd(L, st);
+    }
     const ConvPlan pl = plan_conv(a);
     if (k.Cin != a.cw.Cin || k.Cin % pl.ck != 0 || (a.C1 && a.C0 % pl.ck != 0) || k.CoutPad % 64 != 0) {
         hd_set_error("conv: channel counts must be multiples of the K slice and match the packed weight");

@@ -177,6 +177,15 @@ struct Loader {
             w->wsplit = (unsigned short*)p;
         }
         HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, w->ck, st));
+        if (KH == 3 && !unshuffle && cin % 16 == 0 && cout % 4 == 0) {      // Winograd image of the 3x3 filters (conv_winograd.hip)
+            if (!w->wino) {
+                void* p = nullptr;
+                if (hipMalloc(&p, conv_winograd_weight_bytes(cin, w->CoutPad)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
+                c->owned.push_back(p);
+                w->wino = (unsigned short*)p;
+            }
+            HD_TRY(launch_pack_winograd(w->w, w->wino, cin, w->CoutPad, st));
+        }
         if (bias) HD_TRY(vec(name + ".bias", {cout}, &w->bias));
         return 0;
     }
@@ -987,6 +996,12 @@ int hd_debug_randn(float* out, int B, int S, uint64_t seed, uint64_t tile_offset
     return launch_randn(out, B, S, seed, tile_offset, step, (hipStream_t)stream, noise_stream);
 }
 
+int hd_debug_winograd(int mode) {
+    if (mode < -1 || mode > 1) return HD_EINVAL;
+    conv_set_winograd(mode);
+    return HD_OK;
+}
+
 int hd_debug_capture(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
     c->capture = enable != 0;
@@ -1040,9 +1055,18 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
         rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, cw.ck, st);
         a.cw.wsplit = (unsigned short*)psplit; a.cw.ck = cw.ck; a.precision = HD_PREC_BF16X3;
     }
+    void* pwino = nullptr;
+    if ((mode & 256) && rc == 0) {             // Winograd image + switch: launch_conv takes the F(2x2,3x3) kernel where the shape allows it
+        conv_set_winograd(1);
+        if (KH != 3 || unsh || Cin % 16 || hipMalloc(&pwino, conv_winograd_weight_bytes(Cin, cw.CoutPad)) != hipSuccess) rc = HD_EINVAL;
+        if (rc == 0) rc = launch_pack_winograd(cw.w, (unsigned short*)pwino, Cin, cw.CoutPad, st);
+        a.cw.wino = (unsigned short*)pwino;
+        if (rc == 0 && !conv_uses_winograd(a)) { g_err = "hd_debug_conv: this shape does not take the Winograd kernel"; rc = HD_EINVAL; }
+    }
     if (rc == 0) rc = launch_conv(a, st, nullptr);
+    if (mode & 256) conv_set_winograd(-1);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(pw); if (pst) (void)hipFree(pst); if (psplit) (void)hipFree(psplit);
+    (void)hipFree(pw); if (pst) (void)hipFree(pst); if (psplit) (void)hipFree(psplit); if (pwino) (void)hipFree(pwino);
     return rc;
 }
 

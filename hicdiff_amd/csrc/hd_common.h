@@ -18,6 +18,7 @@ struct Act {
 struct ConvW {
     float* w = nullptr;
     unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/ck][CoutPad][ck hi | ck lo] (fast path)
+    unsigned short* wino = nullptr;     // 3x3 only: Winograd F(2x2,3x3) filter transform, split bf16, MFMA-fragment order (conv_winograd.hip)
     float* bias = nullptr;
     int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;
 };
@@ -96,6 +97,10 @@ int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
                      int standardize, int unshuffle, hipStream_t st);
 int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st);
+size_t conv_winograd_weight_bytes(int Cin, int CoutPad);
+int launch_pack_winograd(const float* packed, unsigned short* dst, int Cin, int CoutPad, hipStream_t st);   // packed: fp32 [9][Cin][CoutPad]
+bool conv_uses_winograd(const ConvArgs& a);   // a.precision must be set
+void conv_set_winograd(int mode);             // -1: HICDIFF_WINOGRAD decides (default off), 0: off, 1: on
 int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st);
 
 int launch_conv_small_cin(const float* x, const float* cond, const float* w, const float* bias, float* out,

@@ -15,7 +15,9 @@ extern "C" {
  *   [Cout][Cin][K][K] (for unshuffle: [Cout][4*Cin][1][1]); mode bits: 1 = nearest x2 upsample,
  *   2 = weight-standardise, 4 = pixel-unshuffle 2x2 stride 2, 8 = affine+SiLU input transform with
  *   A,Bv [B][Cin] (E optional), 16 = LayerNorm input transform (stats computed internally, g = A),
- *   32 = split-bf16 x3 arithmetic instead of exact fp32, 64 = use the 32-channel K slice. */
+ *   32 = split-bf16 x3 arithmetic instead of exact fp32, 64 = use the 32-channel K slice, 128 = LayerNorm statistics passed in Bv,
+ *   256 (with 32; 3x3 only) = also pack the Winograd F(2x2,3x3) filter image, so the convolution runs on conv_winograd.hip -- an
+ *   error if the shape is not one that kernel takes. */
 int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int IH, int IW, const float* w,
                   const float* bias, int Cout, int K, int mode, const float* A, const float* Bv, const float* E,
                   float* out, void* stream);
@@ -69,6 +71,10 @@ int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C, int which,
 int hd_debug_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
 /* hd_debug_linattn_bwd: the LinearAttention core (src/hicdiff.py:212-224: q softmax over d, k softmax over tokens, q * scale, v / n, context, out), any n. */
 int hd_debug_linattn_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
+
+/* The Winograd F(2x2,3x3) form of the eligible 3x3 convolutions (csrc/conv_winograd.hip) is opt-in: 1 = on, 0 = off, -1 = as the
+ * environment says (HICDIFF_WINOGRAD, default off).  Process-wide; contexts pack the Winograd filter image at hd_load_weights either way. */
+int hd_debug_winograd(int mode);
 
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */
 int hd_debug_capture(hd_ctx* ctx, int enable);

@@ -112,6 +112,82 @@ def test_conv3x3_affine_silu_on_load_keeps_zero_padding(prec):
     assert rel_err(ref, run_conv(x, None, w, b, 3, 8 | prec, A=A, Bv=Bv, E=E)) < PRECS[prec]
 
 
+# ---------------------------------------------------------------- Winograd F(2x2,3x3) kernel (conv_winograd.hip)
+WINO = 32 | 256          # split-bf16 x3 products on the Winograd-domain operands
+
+
+@pytest.mark.parametrize("B,S,Cin,Cout", [(2, 16, 64, 64), (1, 64, 16, 128), (1, 32, 128, 256), (3, 16, 48, 192), (5, 32, 64, 64), (2, 48, 32, 68)])
+def test_winograd_conv3x3_plain(B, S, Cin, Cout):
+    x, w, b = rnd(1, B, Cin, S, S), rnd(2, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(3, Cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, WINO)) < 1e-4
+
+
+def test_winograd_asymmetric_filter_orientation():
+    """One non-zero tap at a time: catches a transposed / mirrored filter or tile transform exactly."""
+    x = rnd(1, 1, 16, 16, 16)
+    for ky in range(3):
+        for kx in range(3):
+            w = torch.zeros(64, 16, 3, 3)
+            w[:, :, ky, kx] = rnd(10 + ky * 3 + kx, 64, 16) / 4
+            ref = F.conv2d(x, w, None, padding=1)
+            assert rel_err(ref, run_conv(x, None, w, None, 3, WINO)) < 1e-4, (ky, kx)
+
+
+def test_winograd_concat_standardised_upsample():
+    x0, x1 = rnd(1, 2, 32, 32, 32), rnd(2, 2, 16, 32, 32)
+    w, b = rnd(3, 128, 48, 3, 3) / 20, rnd(4, 128)
+    ref = F.conv2d(torch.cat((x0, x1), 1), w, b, padding=1)
+    assert rel_err(ref, run_conv(x0, x1, w, b, 3, WINO)) < 1e-4
+    x, w, b = rnd(1, 3, 16, 16, 16), rnd(2, 64, 16, 3, 3) * 0.3 + 0.1, rnd(3, 64)
+    mean, var = w.mean(dim=(1, 2, 3), keepdim=True), w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    ref = F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 2 | WINO)) < 1e-4
+    x, w, b = rnd(1, 2, 32, 8, 8), rnd(2, 16, 32, 3, 3) / 17, rnd(3, 16)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1)
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 1 | WINO, out_hw=(16, 16))) < 1e-4
+
+
+@pytest.mark.parametrize("with_e", [False, True])
+def test_winograd_affine_silu_on_load_keeps_zero_padding(with_e):
+    B, Cc, S = 3, 32, 32
+    x, w, b = rnd(1, B, Cc, S, S), rnd(2, 64, Cc, 3, 3) / 17, rnd(3, 64)
+    A, Bv, E = rnd(4, B, Cc) * 0.5 + 1, rnd(5, B, Cc), (rnd(6, B, Cc) if with_e else None)
+    t = F.silu(x * A[:, :, None, None] + Bv[:, :, None, None])
+    if with_e:
+        t = t + E[:, :, None, None]
+    ref = F.conv2d(t, w, b, padding=1)   # padding is applied AFTER the transform
+    assert rel_err(ref, run_conv(x, None, w, b, 3, 8 | WINO, A=A, Bv=Bv, E=E)) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["plain", "affine"])
+def test_winograd_large_grid_is_correct_and_bitwise_reproducible(mode):
+    B, S, Cin = 32, 64, 64
+    x = rnd(1, B, Cin, S, S) * 2 + 0.5
+    if mode == "plain":
+        w, b = rnd(2, 128, Cin, 3, 3) / 24, rnd(3, 128)
+        ref = F.conv2d(x, w, b, padding=1)
+        fn = lambda: run_conv(x, None, w, b, 3, WINO)
+    else:
+        w, b = rnd(2, 64, Cin, 3, 3) / 24, rnd(3, 64)
+        A, Bv = rnd(4, B, Cin) * 0.5 + 1, rnd(5, B, Cin)
+        ref = F.conv2d(F.silu(x * A[:, :, None, None] + Bv[:, :, None, None]), w, b, padding=1)
+        fn = lambda: run_conv(x, None, w, b, 3, 8 | WINO, A=A, Bv=Bv)
+    outs = [fn() for _ in range(3)]
+    assert rel_err(ref, outs[0]) < 1e-4
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_winograd_is_refused_where_the_shape_does_not_fit():
+    x, w = rnd(1, 1, 16, 40, 40), rnd(2, 64, 16, 3, 3)
+    lib = _lib()
+    out = torch.empty((1, 40, 40, 64), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    xd, wd = nhwc(x).cuda(), w.cuda()
+    rc = lib.hd_debug_conv(p(xd), 16, None, 0, 1, 40, 40, p(wd), None, 64, 3, WINO, None, None, None, p(out), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc != 0          # 40x40 is not made of 16x16 blocks: the engine keeps such layers on the implicit-GEMM kernel
+
+
 @pytest.mark.parametrize("mode", ["plain3x3", "affine3x3", "ln1x1", "plain1x1"])
 def test_large_grid_is_correct_and_bitwise_reproducible(mode, prec):
     """Thousands of co-resident workgroups (the regime of the real batch sizes): results must match
@@ -355,3 +431,26 @@ def test_tile_module_writes_the_reference_layout(tmp_path):
         dm.extract_constraint_mats()
     with pytest.raises(RuntimeError):
         PD.split_pieces_device(torch.zeros(8, 8), 8, 8, 40000)   # CPU tensor: no fallback
+
+
+def test_winograd_routes_whole_networks_within_the_parity_bound():
+    """With the opt-in switch on, every eligible layer of the full UNet and of hicedrn (64x64 tiles) runs on the Winograd kernel
+    (input modes, FiLM / residual epilogues, GroupNorm partial sums) and the epsilon forward still meets the per-forward bound."""
+    from _util import golden, product_hicedrn, product_unet
+    lib = _lib()
+    lib.hd_debug_winograd.restype = C.c_int
+    lib.hd_debug_winograd.argtypes = [C.c_int]
+    g = golden("eps")
+    assert lib.hd_debug_winograd(1) == 0
+    try:
+        for kind in ("uncond", "cond", "sr3"):
+            m = product_unet(kind)
+            pre = f"unet_{kind}_s64_"
+            cond = g.get(pre + "cond")
+            out = m(g[pre + "x"].cuda(), g[pre + "t"].cuda(), None if cond is None else cond.cuda())
+            assert rel_err(g[pre + "eps"], out) < 1e-4, kind
+        m = product_hicedrn("cond", 3)
+        out = m(g["hicedrn_cond_n3_s64_x"].cuda(), g["hicedrn_cond_n3_s64_t"].cuda(), g["hicedrn_cond_n3_s64_cond"].cuda())
+        assert rel_err(g["hicedrn_cond_n3_s64_eps"], out) < 1e-4
+    finally:
+        lib.hd_debug_winograd(-1)

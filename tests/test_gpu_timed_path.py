@@ -166,9 +166,9 @@ def test_precision_switch_drops_captured_graphs():
     """hd_set_precision between two chains on the same tensors: the second chain must run the new arithmetic
     (graphs are keyed by tensor addresses, which the caching allocator hands back)."""
     from hicdiff_amd import _lib as L
-    B, S, T = 2, 16, 20
+    B, S, T = 2, 16, 20                                 # the first 20 steps of a 1000-step chain (x0 not yet pinned to the clamp)
     net = product_unet("uncond", 16, (1, 2))
-    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
     eng = net.engine(torch.device("cuda", torch.cuda.current_device()))
     eng.set_precision(L.HD_PRECISION_BF16X3)
     img = d._initial_noise((B, 1, S, S), torch.device("cuda"))
@@ -176,7 +176,7 @@ def test_precision_switch_drops_captured_graphs():
 
     def chain():
         img.copy_(keep)
-        for t in reversed(range(T)):
+        for t in range(999, 999 - T, -1):
             d._step_inplace(img, t, None)
         return img.clone()
 
