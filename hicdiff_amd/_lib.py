@@ -81,6 +81,12 @@ SYMBOLS = {
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "hd_train_loss_backward": (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 3 + [C.c_int, _P, _P]),
     "hd_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
+    "hd_ddrm_x0": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, C.c_size_t, _P]),
+    "hd_ddrm_general_update": (C.c_int, [_P] * 4 + [C.c_int] + [_P] * 3 + [C.POINTER(HdDdrmCoef), _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
+                                          C.c_uint32, _P]),
+    "hd_gather_cols": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "hd_kvec_matmul": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "hd_fwht": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, _P]),
     "hd_split_pieces": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "hd_stitch_pieces": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
 }

@@ -122,6 +122,29 @@ int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
 enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1 };
 int hd_set_precision(hd_ctx* ctx, int mode);
 
+/* ---- DDRM with a general degradation H = U S V^T (src/functions/denoising.py:11-111 over the operators of
+ * src/functions/svd_replacement.py:72-541; HiCDiff itself selects the identity, which hd_ddrm_step fuses).  All tensors are
+ * device fp32; vectors are [B][D] (spectral / pixel space, D = channels * S * S, a multiple of 4) or [B][M] (measurement
+ * space, M singular values). */
+
+/* x0_t = (x_t - eps * sqrt(1 - a_t)) / sqrt(a_t)  (:66); n elements, a multiple of 4. */
+int hd_ddrm_x0(const float* x, const float* eps, float sqrt_at, float sqrt_1m_at, float* x0_out, size_t n, void* stream);
+
+/* The three-case spectral update of one step (:69-104) given V^T x0_t, V^T eps, U^T y and the singular values; `out` is
+ * sqrt(a_next) * (V^T x)_next, to which the caller applies V.  c: sigma_next, sigma_0, etaA/B/C, sqrt_at_next are read.
+ * z0 / z1 / z2: replayed N(0,1) in FULL layout ([B][D], [B][D], [B][M]: the draws of :92, :96 scattered to their elements, :100)
+ * or NULL for device Philox (noise streams 0 / 1 / 2, key (seed, tile_offset + b, step)). */
+int hd_ddrm_general_update(const float* vt_x0, const float* vt_et, const float* ut_y, const float* singulars, int M,
+                           const float* z0, const float* z1, const float* z2, const hd_ddrm_coef* c, float* out, int B, int D,
+                           uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream);
+
+/* Building blocks of the SVD-free operators: dst[b][i] = idx[i] >= 0 ? src[b][idx[i]] : 0 (permutations, selections, zero
+ * padding); dst[n][:] = mat (K x K, row-major, K <= 64) applied to N contiguous K-vectors (src != dst); in-place fast
+ * Walsh-Hadamard transform of N rows of length L = 2^p <= 4096 times `scale`. */
+int hd_gather_cols(const float* src, const int* idx, float* dst, int B, int Dsrc, int Ddst, void* stream);
+int hd_kvec_matmul(const float* src, const float* mat, float* dst, size_t N, int K, void* stream);
+int hd_fwht(float* data, int N, int L, float scale, void* stream);
+
 /* hd_ddpm_step / hd_ddrm_step with device-generated noise replay a captured hipGraph of the whole step
  * (one per (B, S, tensor addresses); the per-step scalars travel through a 1-thread kernel) on a
  * stream owned by the context, ordered after/before the caller's stream by events.  0 disables it

@@ -50,6 +50,9 @@ def create_parser():
     p.add_argument("--target", default=None, help=".npy of high-coverage tiles (N,1,S,S)")
     p.add_argument("--matrix", default=None, help="Full_Mats .npy of one chromosome in [-1,1]: cut into --tile tiles on the GPU (splitPieces), "
                    "degraded with --sigma as split_numpy does, denoised, and stitched back into <out>/predict_matrix.npy")
+    p.add_argument("--data-root", default=None, help="directory holding DataFull/DataFull_<cell>_cell<n>_40000_deno_<sigma>/Splits: the reference's own "
+                   "flow (inference.py:104-118) -- VisionMetrics.getMetrics over the test chromosomes, inds.npy = chromosome of every tile")
+    p.add_argument("--chro", default="test", help="--data-root: 'test' or one chromosome number")
     p.add_argument("--res", type=int, default=40000, help="bin size of --matrix (sets the band of tiles, PrepareData_linear_sing.py:31,42)")
     p.add_argument("--weights", default=None, help="state_dict written by the reference's train.py")
     p.add_argument("--outdir", default=os.path.join(ROOT, "Outputs_diff"))
@@ -68,34 +71,7 @@ def synthetic_tiles(n, s, sigma_0, seed):
     return lq, hq
 
 
-def main(argv=None):
-    args = create_parser().parse_args(argv)
-    conditional = args.conditional or not args.unspervised
-    os.environ["HICDIFF_PRECISION"] = args.precision
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
-    torch.cuda.set_device(device)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    origins = None
-    if args.matrix:
-        from hicdiff_amd.processdata import split_pieces_device
-        full = np.load(args.matrix)
-        tiles_dev, origins = split_pieces_device(torch.from_numpy(np.ascontiguousarray(full, dtype=np.float32)).to(device), args.tile, args.tile, args.res)
-        hq = tiles_dev.cpu()
-        g = torch.Generator().manual_seed(args.seed)
-        lq = hq + (args.sigma if args.sigma <= 1 else 0.1) * torch.randn(hq.shape, generator=g)     # :194-202 with deg='deno'
-    elif args.noisy:
-        lq = torch.from_numpy(np.load(args.noisy)).float()
-        hq = torch.from_numpy(np.load(args.target)).float() if args.target else torch.zeros_like(lq)
-    else:
-        lq, hq = synthetic_tiles(args.synthetic, args.tile, args.sigma if args.sigma <= 1 else 0.1, args.seed)
-    n, S = lq.shape[0], lq.shape[-1]
-
+def build_diffusion(args, conditional, S, device, rank=0):
     torch.manual_seed(args.seed)
     if args.arch == "hicedrn":
         from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
@@ -114,6 +90,65 @@ def main(argv=None):
         print("[inference] no --weights given: seeded random weights (throughput / plumbing runs only)")
     diffusion = diffusion.to(device).eval()
     diffusion.seed = args.seed
+    return diffusion
+
+
+def run_test_split(args, conditional, device):
+    """The reference's Inference() (inference.py:38-118): build the model, hand it to VisionMetrics.getMetrics, which walks the test
+    split through the DataModule and writes Outputs_diff/<name>/{predict,target,noisy,inds}.npy."""
+    diffusion = build_diffusion(args, conditional, args.tile, device)
+    chro = int(args.chro) if str(args.chro).isdigit() else args.chro
+    name = ("hicedrn_l2_" if args.arch == "hicedrn" else "unet_l2_") + args.schedule[:3]
+    out_root = os.path.dirname(os.path.abspath(args.outdir)) if os.path.basename(os.path.normpath(args.outdir)) == "Outputs_diff" else args.outdir
+    if conditional:
+        from hicdiff_amd.Utils import metrics_cond as vm_cond
+        vmx = vm_cond.VisionMetrics(image_channel=1, image_size=args.tile, timestep=args.timesteps, type="condition")
+        predict = vmx.getMetrics(model=diffusion.super_resolution, model_name=name, device=device, chro=chro, deg="deno", sigma=args.sigma,
+                                 cellN=args.celln, cell_line=args.celline, root=args.data_root, outdir=out_root)
+    else:
+        from hicdiff_amd.Utils import metrics_diff as vm
+        vmx = vm.VisionMetrics(image_channel=1, image_size=args.tile, sehedule=args.schedule, timestep=args.sampling_steps)
+        vmx.seed = args.seed
+        predict = vmx.getMetrics(model=diffusion.model, model_name=name, device=device, chro=chro, deg="deno", sigma=args.sigma,
+                                 cellN=args.celln, cell_line=args.celline, root=args.data_root, outdir=out_root)
+    r = vmx.last_result
+    print(f"[inference] {r['nsamples']} tiles -> {vmx.last_dir}")
+    if args.metrics and r["nsamples"]:
+        print(f"[inference] predict vs target: mse {r['mse'] / r['nsamples']:.5f}, psnr {r['psnr']:.4f}, ssim {r['ssim']:.4f}, pcc {r['pcc']:.4f}")
+    return torch.from_numpy(predict)
+
+
+def main(argv=None):
+    args = create_parser().parse_args(argv)
+    conditional = args.conditional or not args.unspervised
+    os.environ["HICDIFF_PRECISION"] = args.precision
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    if args.data_root:
+        return run_test_split(args, conditional, device)
+    origins = None
+    if args.matrix:
+        from hicdiff_amd.processdata import split_pieces_device
+        full = np.load(args.matrix)
+        tiles_dev, origins = split_pieces_device(torch.from_numpy(np.ascontiguousarray(full, dtype=np.float32)).to(device), args.tile, args.tile, args.res)
+        hq = tiles_dev.cpu()
+        g = torch.Generator().manual_seed(args.seed)
+        lq = hq + (args.sigma if args.sigma <= 1 else 0.1) * torch.randn(hq.shape, generator=g)     # :194-202 with deg='deno'
+    elif args.noisy:
+        lq = torch.from_numpy(np.load(args.noisy)).float()
+        hq = torch.from_numpy(np.load(args.target)).float() if args.target else torch.zeros_like(lq)
+    else:
+        lq, hq = synthetic_tiles(args.synthetic, args.tile, args.sigma if args.sigma <= 1 else 0.1, args.seed)
+    n, S = lq.shape[0], lq.shape[-1]
+
+    diffusion = build_diffusion(args, conditional, S, device, rank)
 
     from hicdiff_amd.sharding import sample_sharded
     bs = args.batch_size

@@ -545,7 +545,112 @@ def case_train_unet():
     save("train_unet", **out)
 
 
+def _cpu_shims():
+    """The product's H-function classes are index tables + three HIP primitives; here (no GPU) the primitives are replaced by torch
+    CPU equivalents so the index arithmetic can be checked against the reference operators before any fixture is written."""
+    from hicdiff_amd.functions import svd_replacement as SV
+
+    def gather_cols(src, idx, d_out=None):
+        v = src.reshape(src.shape[0], -1).float()
+        i = idx.long()
+        out = v[:, i.clamp_min(0)]
+        out[:, i < 0] = 0
+        return out
+
+    def kvec_matmul(src, mat):
+        K = mat.shape[0]
+        return (src.reshape(-1, K) @ mat.T).reshape(src.shape)
+
+    SV.gather_cols, SV.kvec_matmul = gather_cols, kvec_matmul
+
+    def fwht(self, vec):
+        a = vec.reshape(vec.shape[0], self.channels, self.img_dim ** 2).clone().float()
+        h, L = 1, self.img_dim ** 2
+        while h < L:
+            a = a.reshape(vec.shape[0], self.channels, -1, 2 * h)
+            lo, hi = a[..., :h].clone(), a[..., h:].clone()
+            a[..., :h], a[..., h:] = lo + hi, lo - hi
+            h *= 2
+        return a.reshape(vec.shape[0], self.channels, L) / self.img_dim
+
+    SV.WalshHadamardCS.fwht = fwht
+    return SV
+
+
+def _dense(H, D, M):
+    """Rows = what the operator does to the unit vectors: V_rows[k] = V e_k etc."""
+    eD, eM = torch.eye(D), torch.eye(M)
+    return {"V": H.V(eD.clone()).reshape(D, -1), "Vt": H.Vt(eD.clone()).reshape(D, -1), "U": H.U(eM.clone()).reshape(M, -1), "Ut": H.Ut(eM.clone()).reshape(M, -1)}
+
+
+def case_ddrm_general():
+    """SURVEY row f-4, the non-identity degradations (src/functions/svd_replacement.py:72-541, H_func.py:4-67) at 8 x 8:
+    every operator as dense matrices, and DDRM chains (10 of 1000 steps, tiny UNet) for the ones a 1-channel network can drive."""
+    from src.functions import svd_replacement as RS
+    SV = _cpu_shims()
+    from hicdiff_amd.functions import H_func as PH
+    out = {}
+    S, B = 8, 2
+    betas = ODR.ddrm_betas("linear")
+    seq = range(0, 1000, 100)
+    m, cfg = build_unet("uncond", 16, (1, 2))
+    model_o = oracle_model(m, cfg)
+    hq = tiles(31, B, S)
+
+    def ref_and_mine(deg, C_):
+        torch.manual_seed(777)
+        Hr = MakeFunc(deg, C_, S, device="cpu")
+        torch.manual_seed(777)
+        Hm = PH.MakeFunc(deg, C_, S, device="cpu")
+        return Hr, Hm
+
+    for deg, C_ in (("inp_mask", 1), ("sr2", 1), ("sr4", 1), ("deblur_uni", 1), ("deblur_gauss", 1), ("deblur_aniso", 1), ("cs2", 1), ("cs4", 1),
+                    ("color", 3), ("sr_bicubic2", 3), ("inp_mask", 3), ("sr2", 3)):
+        Hr, Hm = ref_and_mine(deg, C_)
+        D = C_ * S * S
+        s_r = Hr.singulars()
+        M = Hr.Ut(Hr.H(torch.zeros(1, D))).shape[1] if deg != "sr_bicubic2" else (S // 2) ** 2 * C_
+        dr, dm = _dense(Hr, D, M), _dense(Hm, D, M)
+        tag = f"{deg}_c{C_}"
+        for k in dr:
+            check(f"{tag} product index tables: {k}", dr[k], dm[k], tol=1e-5)
+        check(f"{tag} singulars", s_r, Hm.singulars(), tol=1e-6)
+        pre = tag + "_"
+        out[pre + "V"], out[pre + "Vt"], out[pre + "U"], out[pre + "Ut"], out[pre + "s"] = dr["V"], dr["Vt"], dr["U"], dr["Ut"], s_r
+        if deg == "inp_mask":
+            out[pre + "missing"] = Hr.missing_indices
+        if deg[:2] == "cs":
+            out[pre + "perm"] = Hr.perm
+        if deg.startswith("deblur") or deg.startswith("sr_bicubic"):       # the small SVD factors: LAPACK may pick other signs elsewhere
+            if deg == "deblur_aniso":
+                for nm in ("U_small1", "singulars_small1", "V_small1", "U_small2", "singulars_small2", "V_small2"):
+                    out[pre + nm] = getattr(Hr, nm)
+            else:
+                for nm in ("U_small", "singulars_small", "V_small"):
+                    out[pre + nm] = getattr(Hr, nm)
+        if C_ != 1 or deg in ("sr4", "cs4"):
+            continue
+        # chain: y_0 = H x + sigma_0 n; the reference's sampler against the oracle's on replayed noise
+        sigma_0 = 0.1
+        y0 = Hr.H(hq) + sigma_0 * gauss(32, (B, M))
+        torch.manual_seed(2025)
+        x = torch.randn(B, 1, S, S)
+        xs, x0s = efficient_generalized_steps(x, seq, m, betas, Hr, y0, sigma_0, etaB=1.0, etaA=0.85, etaC=0.85)
+        nz = OD.TorchNoise(2025)
+        x_m = nz.randn((B, 1, S, S))
+        assert torch.equal(x, x_m)
+        # the oracle sees the operator only as dense matrices: V e_k are the columns
+        Ho = ODR.DenseH(dr["V"].T, dr["U"].T, s_r)
+        mine, x0_m = ODR.ddrm_general(x_m, seq, model_o, betas, Ho, y0, sigma_0, noise=nz)
+        check(f"{tag} ddrm chain final", xs[-1], mine, tol=5e-4)
+        check(f"{tag} ddrm chain x0", x0s[-1], x0_m, tol=5e-4)
+        out[pre + "y0"], out[pre + "final"], out[pre + "x0_last"] = y0, xs[-1], x0s[-1]
+    out["hq"] = hq
+    save("ddrm_general", **out)
+
+
 CASES = {
+    "ddrm_general": case_ddrm_general,
     "train_unet": case_train_unet,
     "train": case_train,
     "tiles": case_tiles,

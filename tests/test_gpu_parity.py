@@ -305,3 +305,70 @@ def test_inference_cli_whole_chromosome(tmp_path, precision):
     mat = np.load(out / "predict_matrix.npy")
     assert mat.shape == (n, n)
     assert np.array_equal(mat, OT.stitch_pieces(np.load(out / "predict.npy"), OT.tile_origins(n, 16, 16, 40000)[0], n))
+
+
+def _write_full_mats(root, cell, celln, sigma, sizes, res=40000):
+    """Synthetic Full_Mats of a few chromosomes: what extract_create_numpy would have left (symmetric, in [-1, 1])."""
+    import os
+    d = f"{root}/DataFull/DataFull_{cell}_cell{celln}_{res}_deno_{sigma}/Full_Mats"
+    os.makedirs(d, exist_ok=True)
+    for c, n in sizes.items():
+        g = torch.Generator().manual_seed(100 + c)
+        a = 2 * torch.rand((n, n), generator=g) ** 3 - 1
+        np.save(f"{d}/GSE131811_mat_full_chr_{c}_{res}.npy", ((a + a.T) / 2).numpy())
+
+
+def test_vision_metrics_walks_the_test_split_and_writes_chromosome_inds(tmp_path, precision):
+    """The reference's evaluation flow (inference.py:104-118 -> src/Utils/metrics_diff.py:121-224, metrics_cond.py:61-137):
+    VisionMetrics.getMetrics(model) iterates the DataModule's test split, and inds.npy holds the chromosome of every tile."""
+    if precision != "bf16x3":
+        pytest.skip("one arithmetic mode is enough for the driver")
+    import inference
+    from hicdiff_amd.processdata import tile_origins
+    sizes = {1: 40, 2: 33, 3: 48, 4: 16, 5: 70, 6: 20}                     # Drosophila: six chromosomes, all in the test split
+    _write_full_mats(tmp_path, "Dros", 2, 0.1, sizes)
+    want_inds = np.concatenate([np.repeat(c, len(tile_origins(n, 16, 16, 40000)[0])) for c, n in sizes.items()])
+    common = ["-l", "Dros", "-n", "2", "-s", "0.1", "--resnet-blocks", "2", "--tile", "16", "--data-root", str(tmp_path),
+              "--outdir", str(tmp_path / "Outputs_diff"), "--metrics"]
+    pred = inference.main(["-u", "1", "--sampling-steps", "10", "--schedule", "linear"] + common)
+    out = tmp_path / "Outputs_diff" / "hicedrn_l2_linDros2_deno_0.1_trans2_10"
+    inds = np.load(out / "inds.npy")
+    assert np.array_equal(inds, want_inds) and pred.shape == (len(want_inds), 1, 16, 16) and torch.isfinite(pred).all()
+    target, noisy = np.load(out / "target.npy"), np.load(out / "noisy.npy")
+    assert target.shape == noisy.shape == tuple(pred.shape) and np.array_equal(np.load(out / "predict.npy"), pred.numpy())
+    # the files are the DataModule's Splits in chromosome order
+    base = f"{tmp_path}/DataFull/DataFull_Dros_cell2_40000_deno_0.1/Splits"
+    assert np.array_equal(target, np.concatenate([np.load(f"{base}/GSE131811_full_chr_{c}_40000_piece_16.npy") for c in sizes]))
+    # conditional flow: the bound method diffusion.super_resolution goes in, as upstream
+    pred2 = inference.main(["-u", "", "--timesteps", "50", "--schedule", "linear"] + common)
+    out2 = tmp_path / "Outputs_diff" / "hicedrn_l2_linDros2_deno_0.1_test_condition"
+    assert np.array_equal(np.load(out2 / "inds.npy"), want_inds) and pred2.shape == pred.shape
+    # one chromosome only
+    pred3 = inference.main(["-u", "1", "--sampling-steps", "5", "--schedule", "linear", "--chro", "5"] + common)
+    assert pred3.shape[0] == (want_inds == 5).sum()
+
+
+def test_vision_metrics_object_api(tmp_path, precision):
+    """Direct use as in the reference: vm.VisionMetrics(...).getMetrics(model=diffusion.model, ...); the chain equals the one
+    efficient_generalized_steps produces by hand on the same tiles (device noise keyed by the tile's position in the set)."""
+    if precision != "bf16x3":
+        pytest.skip("one arithmetic mode is enough")
+    from hicdiff_amd.Utils import metrics_diff as vm
+    from hicdiff_amd.functions.H_func import MakeFunc
+    from hicdiff_amd.functions.denoising import efficient_generalized_steps
+    from hicdiff_amd.processdata import GSE131811Module
+    _write_full_mats(tmp_path, "Dros", 3, 0.1, {c: 32 for c in range(1, 7)})
+    m = product_hicedrn("uncond", 2)
+    v = vm.VisionMetrics(image_channel=1, image_size=16, sehedule="linear", timestep=10)
+    v.seed = 99
+    pred = v.getMetrics(model=m, model_name="hicedrn_l2_lin", device="cuda", chro="test", deg="deno", sigma=0.1, cellN=3, cell_line="Dros",
+                        root=str(tmp_path))
+    assert pred.shape == (18, 1, 16, 16) and v.last_result["nsamples"] == 18 and 0 < v.last_result["ssim"] <= 1
+    assert torch.equal(v.betas.cpu(), torch.from_numpy(np.linspace(1e-4, 0.02, 1000, dtype=np.float64)).float())
+    dm = GSE131811Module(batch_size=64, piece_size=16, cell_No=3, sigma_0=0.1, root=str(tmp_path))
+    dm.setup("test")
+    sp = dm.test_set.samp.cuda()
+    x = m.engine(torch.device("cuda", 0)).randn(18, 16, 99, 0, 1 << 20)
+    xs, _ = efficient_generalized_steps(x, range(0, 1000, 100), m, v.betas.cuda(), MakeFunc("deno", 1, 16, "cuda"), sp, 0.1, etaB=1.0, etaA=0.85,
+                                        etaC=0.85, seed=99, tile_offset=0)
+    assert torch.equal(torch.from_numpy(pred), xs[-1].cpu())

@@ -164,31 +164,36 @@ def test_graph_replayed_ddrm_chain_vs_oracle(net_kind, sigma_0, precision):
 
 def test_precision_switch_drops_captured_graphs():
     """hd_set_precision between two chains on the same tensors: the second chain must run the new arithmetic
-    (graphs are keyed by tensor addresses, which the caching allocator hands back)."""
+    (graphs are keyed by tensor addresses, which stay the same here).  DDRM steps: no clamp hides the difference."""
     from hicdiff_amd import _lib as L
-    B, S, T = 2, 16, 20                                 # the first 20 steps of a 1000-step chain (x0 not yet pinned to the clamp)
+    B, S = 2, 16
     net = product_unet("uncond", 16, (1, 2))
-    d = diffusion_class("uncond")(net, image_size=S, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
     eng = net.engine(torch.device("cuda", torch.cuda.current_device()))
     eng.set_precision(L.HD_PRECISION_BF16X3)
-    img = d._initial_noise((B, 1, S, S), torch.device("cuda"))
-    keep = img.clone()
+    keep = device_randn(B, S, 3, 0, 1)
+    y = (tiles(4, B, S).cuda() * 0.5).contiguous()
+    x, x0 = keep.clone(), torch.empty_like(keep)
+    co = L.HdDdrmCoef()
+    co.sqrt_at, co.sqrt_1m_at, co.sqrt_at_next, co.sigma_next, co.sigma_0 = 0.8, 0.6, 0.85, 0.62, 1.0   # sigma_next < sigma_0: the branch that keeps x0_t
+    co.etaA, co.etaB, co.etaC, co.time_value = 0.85, 1.0, 0.85, 300.0
 
     def chain():
-        img.copy_(keep)
-        for t in range(999, 999 - T, -1):
-            d._step_inplace(img, t, None)
-        return img.clone()
+        x.copy_(keep)
+        for k in range(6):                  # call 1 eager, call 2 captures, calls 3.. replay
+            eng.ddrm_step(x, y, None, co, x0, seed=11, tile_offset=0, step=k)
+        return x.clone(), x0.clone()
 
-    fast = chain()
+    fast, fast0 = chain()
     eng.set_precision(L.HD_PRECISION_F32)
-    exact = chain()                         # same `img` address: a stale graph would replay the bf16x3 kernels
+    exact, exact0 = chain()                 # same tensor addresses: a stale graph would replay the bf16x3 kernels
     _set_graphs(net, False)
-    exact_eager = chain()
+    exact_eager, _ = chain()
     _set_graphs(net, True)
     eng.set_precision(L.HD_PRECISION_BF16X3)
+    again, _ = chain()
     assert torch.equal(exact, exact_eager)
-    assert not torch.equal(exact, fast)
+    assert not torch.equal(exact0, fast0)
+    assert torch.equal(again, fast)
     assert rel_err(exact, fast) < CHAIN_TOL
 
 

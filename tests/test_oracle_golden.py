@@ -241,3 +241,25 @@ def test_train_oracle_reproduces_reference_unet_gradients(kind):
     for k in sd:
         ref = torch.from_numpy(g[f"{kind}_s1_grad_sample/{k}"])
         assert float((OTR.sample_of(grads[k]) - ref).abs().max()) <= 5e-5 * max(float(ref.abs().max()), 1e-12), k
+
+
+GENERAL_CHAINS = ("inp_mask", "sr2", "deblur_uni", "deblur_gauss", "deblur_aniso", "cs2")
+
+
+@pytest.mark.parametrize("deg", GENERAL_CHAINS)
+def test_ddrm_general_chain_golden(deg):
+    """the oracle's general DDRM sampler (operator given as the dense matrices the reference's own V / U
+    methods produce) reproduces the reference's chains on replayed noise."""
+    from oracle import ddrm as ODR, diffusion as OD
+    g = golden("ddrm_general")
+    pre = f"{deg}_c1_"
+    H = ODR.DenseH(g[pre + "V"].T, g[pre + "U"].T, g[pre + "s"])
+    model = oracle_unet("uncond", 16, (1, 2))
+    nz = OD.TorchNoise(2025)
+    x = nz.randn((2, 1, 8, 8))
+    out, x0 = ODR.ddrm_general(x, range(0, 1000, 100), model, ODR.ddrm_betas("linear"), H, g[pre + "y0"], 0.1, noise=nz)
+    assert rel_err(g[pre + "final"], out) < CHAIN_TOL
+    assert rel_err(g[pre + "x0_last"], x0) < CHAIN_TOL
+    # V is orthogonal and V^T its transpose, as the sampler assumes
+    V = g[pre + "V"]
+    assert torch.allclose(V @ V.T, torch.eye(V.shape[0]), atol=2e-5) and torch.allclose(g[pre + "Vt"], V.T, atol=2e-5)
