@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs on torch's intra-op pool.  A GPU box shows every host core but grants this job a share of 16: with the default
+    # (one thread per visible core) the oracle's convolutions crawl under oversubscription.
+    import torch
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(cores, int(os.environ.get("HICDIFF_CPU_THREADS", "16")))))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -5,7 +5,7 @@
 
 It runs, each as its own rocprofv3 invocation (counters never share a run with --stats; the program after `--` is python3
 itself, no wrapper):
-  1. rocprofv3 --kernel-trace --stats  -- python3 bench.py                      kernel_stats.csv + the bench JSON line
+  1. rocprofv3 --kernel-trace --stats  -- python3 bench.py --sustained-budget 0        kernel_stats.csv + the bench JSON line
   2. rocprofv3 --kernel-trace --stats  -- python3 bench.py --workload hicedrn64 --steps 5 --warmup 1
   3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
   4. rocprofv3 --kernel-trace --pmc WRITE_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
@@ -92,9 +92,11 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "profiles")
     os.makedirs(work, exist_ok=True)
     os.makedirs(out, exist_ok=True)
-    rocprof(os.path.join(work, "unet64"), ["--stats"], [], os.path.join(work, "unet64.log"))
-    rocprof(os.path.join(work, "hicedrn64"), ["--stats"], ["--workload", "hicedrn64", "--steps", "5", "--warmup", "1"], os.path.join(work, "hicedrn64.log"))
-    short = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    # --sustained-budget 0: the post-timing whole-chain run (1000 more steps) would only bloat the traces
+    rocprof(os.path.join(work, "unet64"), ["--stats"], ["--sustained-budget", "0"], os.path.join(work, "unet64.log"))
+    rocprof(os.path.join(work, "hicedrn64"), ["--stats"], ["--workload", "hicedrn64", "--steps", "5", "--warmup", "1", "--sustained-budget", "0"],
+            os.path.join(work, "hicedrn64.log"))
+    short = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-budget", "0"]
     rocprof(os.path.join(work, "fetch"), ["--pmc", "FETCH_SIZE"], short, os.path.join(work, "fetch.log"))
     rocprof(os.path.join(work, "write"), ["--pmc", "WRITE_SIZE"], short, os.path.join(work, "write.log"))
     if "--no-sq" not in sys.argv:
