@@ -267,8 +267,7 @@ class DiffusionCore(nn.Module):
 
     @torch.no_grad()
     def ddim_sample(self, shape, return_all_timesteps=False):
-        """src/hicdiff.py:622-664.  The epsilon-network runs on the HIP engine; the few per-step
-        scalar-tensor updates are device elementwise ops."""
+        """src/hicdiff.py:622-664 on the fused step of the HIP engine."""
         eng = self.model.engine(self._device())
         saved = eng.precision
         # Strided DDIM divides eps by sqrt(alpha_bar) at a few, far-apart steps with no noise to wash the
@@ -281,26 +280,34 @@ class DiffusionCore(nn.Module):
             eng.set_precision(saved)
 
     def _ddim_sample(self, shape, return_all_timesteps=False):
+        """Each DDIM step is the same fused call as the ancestral step (hd_ddpm_step: eps-net + clamp + update + noise, hipGraph
+        replay with device noise) with other coefficients: x <- sqrt(a_next) x0 + sqrt(1 - a_next - sigma^2) eps + sigma z."""
         shape = tuple(shape)
-        batch, device, T, S, eta = shape[0], self._device(), self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        device, T, S, eta = self._device(), self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        if self.objective != "pred_noise":
+            raise NotImplementedError("the fused sampler implements objective='pred_noise' (the only one the reference drivers use)")
         times = list(reversed(torch.linspace(-1, T - 1, steps=S + 1).int().tolist()))
-        ac = self._host["alphas_cumprod"]
+        h = self._host
+        ac = h["alphas_cumprod"]
+        eng = self.model.engine(device)
         img = self._initial_noise(shape, device)
         imgs = [img.clone()] if return_all_timesteps else None
-        for k, (time, time_next) in enumerate(zip(times[:-1], times[1:])):
-            tc = torch.full((batch,), time, device=device, dtype=torch.long)
-            pred_noise, x_start = self.model_predictions(img, tc, None, clip_x_start=True)
-            if time_next < 0:
-                img = x_start
+        for time, time_next in zip(times[:-1], times[1:]):
+            c = L.HdDdpmCoef()
+            c.sqrt_recip_alphas_cumprod = float(h["sqrt_recip_alphas_cumprod"][time])
+            c.sqrt_recipm1_alphas_cumprod = float(h["sqrt_recipm1_alphas_cumprod"][time])
+            c.time_value = float(time)
+            c.posterior_mean_coef2 = 0.0
+            noise = None
+            if time_next < 0:                      # last step: x_0 itself (src/hicdiff.py:642-645)
+                c.posterior_mean_coef1, c.eps_coef, c.sigma = 1.0, 0.0, 0.0
             else:
                 a, an = ac[time], ac[time_next]
                 sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
-                c = (1 - an - sigma ** 2).sqrt()
-                if self.noise_source is not None:
-                    noise = self.noise_source.randn(shape)
-                else:
-                    noise = self.model.engine(device).randn(batch, shape[2], self.seed, self.tile_offset, time)
-                img = x_start * float(an.sqrt()) + float(c) * pred_noise + float(sigma) * noise
+                c.posterior_mean_coef1, c.eps_coef, c.sigma = float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
+                if self.noise_source is not None:      # the reference draws randn_like(img) at every such step, eta = 0 included
+                    noise = self.noise_source.randn(shape).contiguous()
+            eng.ddpm_step(img, None, noise, c, None, seed=self.seed, tile_offset=self.tile_offset, step=time)
             if return_all_timesteps:
                 imgs.append(img.clone())
         ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)

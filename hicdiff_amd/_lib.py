@@ -36,7 +36,7 @@ class HdDdpmCoef(C.Structure):
     _fields_ = [
         ("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
         ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
-        ("sigma", C.c_float), ("time_value", C.c_float),
+        ("sigma", C.c_float), ("time_value", C.c_float), ("eps_coef", C.c_float),
     ]
 
 

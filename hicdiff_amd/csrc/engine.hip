@@ -804,7 +804,7 @@ static int step_body(hd_ctx* c, int kind, float* x, const float* aux, const floa
     const float* cond = kind == 0 ? aux : nullptr;
     HD_TRY(forward(c, x, nullptr, HD_T_FLOAT32, v.f[0], true, cond, c->eps_buf, B, S, st, false, sp));
     if (kind == 0)
-        return launch_ddpm_update(x, c->eps_buf, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], x0_out, B, S, v.seed, v.tile_off, v.step, sp, st);
+        return launch_ddpm_update(x, c->eps_buf, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], x0_out, B, S, v.seed, v.tile_off, v.step, sp, st, v.f[6]);
     return launch_ddrm_update(x, c->eps_buf, aux, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], v.f[6], v.f[7], v.f[8], x0_out, B, S, v.seed,
                               v.tile_off, v.step, sp, st);
 }
@@ -860,7 +860,7 @@ int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, con
     if ((c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
     StepParams v{};
     v.f[0] = k->time_value; v.f[1] = k->sqrt_recip_alphas_cumprod; v.f[2] = k->sqrt_recipm1_alphas_cumprod;
-    v.f[3] = k->posterior_mean_coef1; v.f[4] = k->posterior_mean_coef2; v.f[5] = k->sigma;
+    v.f[3] = k->posterior_mean_coef1; v.f[4] = k->posterior_mean_coef2; v.f[5] = k->sigma; v.f[6] = k->eps_coef;
     v.step = step; v.seed = seed; v.tile_off = tile_offset;
     return keep_err(c, run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream));
 }

@@ -27,7 +27,7 @@ enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
 
 // Per-step scalars of a fused sampler step, resident in device memory when the step is replayed from a
 // hipGraph: f[0] = time value; ddpm: f[1..5] = recip, recipm1, coef1, coef2, sigma; ddrm: f[1..8] =
-// sqrt_at, sqrt_1m_at, sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC.
+// sqrt_at, sqrt_1m_at, sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC; ddpm also f[6] = weight of eps itself (DDIM steps).
 struct StepParams { float f[12]; uint32_t step; uint32_t pad; uint64_t seed; uint64_t tile_off; };
 
 enum InMode { IN_NONE = 0, IN_AFFINE_SILU = 1, IN_LAYERNORM = 2, IN_SOFTMAX32 = 4 };   // 4: softmax over every 32-channel group (LinearAttention q, src/hicdiff.py:217); bf16x3 kernel only
@@ -155,7 +155,7 @@ int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hip
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,
                        float coef2, float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off,
-                       uint32_t step, const StepParams* sp, hipStream_t st);
+                       uint32_t step, const StepParams* sp, hipStream_t st, float coef_eps = 0.f);
 int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
                        float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC,
                        float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,

@@ -630,11 +630,11 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
                                                           const float* __restrict__ noise, float c_recip, float c_recipm1,
                                                           float coef1, float coef2, float sigma, float* __restrict__ x0_out, int B,
                                                           int SS4, uint64_t seed, uint64_t tile_off, uint32_t step,
-                                                          const StepParams* __restrict__ sp) {
+                                                          const StepParams* __restrict__ sp, float coef_eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * SS4) return;
     if (sp) {
-        c_recip = sp->f[1]; c_recipm1 = sp->f[2]; coef1 = sp->f[3]; coef2 = sp->f[4]; sigma = sp->f[5];
+        c_recip = sp->f[1]; c_recipm1 = sp->f[2]; coef1 = sp->f[3]; coef2 = sp->f[4]; sigma = sp->f[5]; coef_eps = sp->f[6];
         seed = sp->seed; tile_off = sp->tile_off; step = sp->step;
     }
     const float4 xv = reinterpret_cast<float4*>(x)[i];
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
     float4 x0, o;
 #define HD_STEP(f)                                                           \
     x0.f = fminf(fmaxf(c_recip * xv.f - c_recipm1 * ev.f, -1.f), 1.f);      \
-    o.f = coef1 * x0.f + coef2 * xv.f + sigma * z.f;
+    o.f = coef1 * x0.f + coef2 * xv.f + coef_eps * ev.f + sigma * z.f;
     HD_STEP(x) HD_STEP(y) HD_STEP(z) HD_STEP(w)
 #undef HD_STEP
     reinterpret_cast<float4*>(x)[i] = o;
@@ -656,11 +656,11 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1, float coef2,
                        float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
-                       hipStream_t st) {
+                       hipStream_t st, float coef_eps) {
     if ((S * S) % 4) { hd_set_error("tile size must make S*S a multiple of 4"); return -1; }
     const int SS4 = S * S / 4;
     hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)(((size_t)B * SS4 + 255) / 256)), dim3(256), 0, st, x, eps, noise, c_recip,
-                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step, sp);
+                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step, sp, coef_eps);
     return check_launch("ddpm_update");
 }
 

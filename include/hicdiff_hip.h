@@ -82,6 +82,8 @@ typedef struct {
     float posterior_mean_coef2;
     float sigma;                         /* exp(0.5 * posterior_log_variance_clipped[t]); 0 at t == 0 */
     float time_value;                    /* value fed to the time embedding: t, or the SR3 noise level */
+    float eps_coef;                      /* weight of eps itself in the update; 0 for the ancestral step.  A DDIM step (src/hicdiff.py:622-664) is
+                                            coef1 = sqrt(alpha_next), coef2 = 0, eps_coef = sqrt(1 - alpha_next - sigma^2), sigma = eta-term */
 } hd_ddpm_coef;
 
 /* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
@@ -164,7 +166,7 @@ int hd_eps_forward(hd_ctx* ctx, const float* x, const void* t, int t_kind, const
 /* One fused ancestral step, GaussianDiffusion.p_sample (src/hicdiff.py:594-601; conditional
  * src/hicdiff_condition.py:592-598; SR3 src/hicdiff_sr3.py:634-652):
  *   eps = model(x, t, cond); x0 = clamp(c.recip * x - c.recipm1 * eps, -1, 1);
- *   x <- c.coef1 * x0 + c.coef2 * x + c.sigma * noise.
+ *   x <- c.coef1 * x0 + c.coef2 * x + c.eps_coef * eps + c.sigma * noise.
  * noise: (B,1,S,S) host-replayed N(0,1) for parity runs, or NULL to draw it on the device
  * (Philox4x32-10 keyed by (seed, tile_offset + tile, step)); x0_out optional (may be NULL). */
 int hd_ddpm_step(hd_ctx* ctx, float* x_inout, const float* cond, const float* noise,

@@ -172,6 +172,35 @@ def test_graph_replayed_ddrm_chain_vs_oracle(net_kind, sigma_0, precision):
     assert torch.equal(xs2[-1], xs[-1])
 
 
+@pytest.mark.parametrize("eta", [0.0, 0.5])
+def test_graph_replayed_ddim_vs_oracle(eta):
+    """DDIM (src/hicdiff.py:622-664) on the fused step: 20 of 1000 steps with device noise, graph replay, against the oracle over the
+    same noise (x_T keyed by step = T, the z of a step by its timestep), and bit-identical to the eager launch."""
+    from oracle import diffusion as OD
+    B, S, T, n, seed = 2, 40, 1000, 20, 606
+    net = product_unet("uncond")
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, sampling_timesteps=n, loss_type="l2", beta_schedule="sigmoid",
+                                  ddim_sampling_eta=eta).cuda()
+    d.seed = seed
+    got = d.sample(torch.zeros(B, 1, S, S))
+    times = list(reversed(torch.linspace(-1, T - 1, steps=n + 1).int().tolist()))
+
+    class Replay:
+        def __init__(self):
+            self.keys = iter([T] + [t for t, tn in zip(times[:-1], times[1:]) if tn >= 0])
+
+        def randn(self, shape):
+            return device_randn(B, S, seed, 0, next(self.keys)).cpu()
+
+    ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=S, timesteps=T, beta_schedule="sigmoid", sampling_timesteps=n, ddim_sampling_eta=eta)
+    want = ref.ddim_sample((B, 1, S, S), Replay())
+    assert rel_err(want, got) < CHAIN_TOL
+    _set_graphs(net, False)
+    eager = d.sample(torch.zeros(B, 1, S, S))
+    _set_graphs(net, True)
+    assert torch.equal(eager, got)
+
+
 def test_precision_switch_drops_captured_graphs():
     """hd_set_precision between two chains on the same tensors: the second chain must run the new arithmetic
     (graphs are keyed by tensor addresses, which stay the same here).  DDRM steps: no clamp hides the difference."""

@@ -115,8 +115,11 @@ def test_product_path_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         net(torch.zeros(1, 1, 16, 16), torch.zeros(1, dtype=torch.long))
     from hicdiff_amd.functions.H_func import MakeFunc
-    with pytest.raises(NotImplementedError):
-        MakeFunc("sr4", 1, 16)
+    sr = MakeFunc("sr4", 1, 16, device="cpu")              # the operator's tables are built on the host; applying it needs the GPU
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sr.Vt(torch.zeros(1, 1, 16, 16))
+    with pytest.raises(ValueError):
+        MakeFunc("no_such_degradation", 1, 16)
     H = MakeFunc("deno", 1, 4)
     v = torch.arange(32.).reshape(2, 1, 4, 4)
     assert torch.equal(H.H(v), v.reshape(2, -1)) and torch.equal(H.H_pinv(v), v.reshape(2, -1))
