@@ -2,6 +2,7 @@
 // input channels, time embedding + FiLM projections, GroupNorm statistics, channel LayerNorm, linear
 // and full attention, and the fused sampler updates.  Activations are NHWC fp32.
 #include "hd_common.h"
+#include <cstdlib>
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
@@ -580,7 +581,14 @@ __global__ __launch_bounds__(256) void attn_full_kernel(const float* __restrict_
     for (int d = 0; d < D; d += 4) *reinterpret_cast<float4*>(o + d) = make_float4(acc[d] * inv, acc[d + 1] * inv, acc[d + 2] * inv, acc[d + 3] * inv);
 }
 
+int launch_attn_full_mfma(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st);   // attn_mfma.hip; returns 1 when the shape is not its
+
 int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hipStream_t st) {
+    static const bool no_mfma = getenv("HICDIFF_ATTN_SCALAR") != nullptr;
+    if (!no_mfma) {
+        const int rc = launch_attn_full_mfma(qkv, B, HW, heads, out, st);
+        if (rc <= 0) return rc;
+    }
     const int qchunks = (HW + 255) / 256;
     hipLaunchKernelGGL(attn_full_kernel, dim3(B * heads * qchunks), dim3(256), 0, st, qkv, HW, heads, out);
     return check_launch("attn_full");
