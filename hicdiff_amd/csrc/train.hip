@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <deque>
+#include <map>
 #include <string>
 #include <vector>
 

@@ -333,6 +333,7 @@ def test_train_plain_bf16_option():
     val2.backward()
     assert torch.equal(val, val2) and all(torch.equal(first[k], p.grad) for k, p in d.model.named_parameters())
     opt = Adam(d.parameters(), lr=2e-4)
+    opt.zero_grad()                                         # (gradients accumulate over backward() calls, as in torch: start the run clean)
     om, ov = {k: torch.zeros_like(v) for k, v in sd.items()}, {k: torch.zeros_like(v) for k, v in sd.items()}
     for step in range(1, 11):
         gen = torch.Generator().manual_seed(100 + step)
