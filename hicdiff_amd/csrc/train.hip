@@ -140,12 +140,13 @@ __device__ __forceinline__ uint4 shift_next(const uint4& c, unsigned nextx) {   
                       __builtin_amdgcn_alignbit(c.w, c.z, 16), __builtin_amdgcn_alignbit(nextx, c.w, 16));
 }
 
-template <bool PLAIN, bool ONE>      // PLAIN: hi x hi only -- no lo images are loaded, staged or multiplied.  ONE: 1x1 filter, centre tap only
+template <bool PLAIN, bool ONE, int TMW = 2>      // PLAIN: hi x hi only -- no lo images are loaded, staged or multiplied.  ONE: 1x1 filter, centre tap only.
+// TMW: 32-row blocks per wave: 2 = 128 input channels per workgroup, 1 = 64 (layers with 64 input channels: no padded half)
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
                                                             const unsigned short* __restrict__ Ghi, const unsigned short* __restrict__ Glo,
                                                             size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int F,
                                                             float* __restrict__ partial, int xcd_group) {
-    constexpr int BM = 128, BN = 64, KS = 64, PA = KS * 2 + 16, PG = (KS + 16) * 2 + 16;      // 144, 176 bytes
+    constexpr int BM = 64 * TMW, BN = 64, KS = 64, PA = KS * 2 + 16, PG = (KS + 16) * 2 + 16;      // 144, 176 bytes
     __shared__ __attribute__((aligned(16))) char sA[2][BM * PA];
     __shared__ __attribute__((aligned(16))) char sG[2][BN * PG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
@@ -178,33 +179,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
 #define HD_LD(p, j, K) (*reinterpret_cast<const uint4*>((p) + (size_t)(j) * 32 * ld + (K)))
 #define HD_LG(j, K) (*reinterpret_cast<const uint4*>(pg##j + (K)))
 #define HD_GLOAD(K)                                                                                  \
-    rAh0 = HD_LD(pAh, 0, K); rAh1 = HD_LD(pAh, 1, K); rAh2 = HD_LD(pAh, 2, K); rAh3 = HD_LD(pAh, 3, K);     \
-    if constexpr (!PLAIN) { rAl0 = HD_LD(pAl, 0, K); rAl1 = HD_LD(pAl, 1, K); rAl2 = HD_LD(pAl, 2, K); rAl3 = HD_LD(pAl, 3, K); } \
+    rAh0 = HD_LD(pAh, 0, K); rAh1 = HD_LD(pAh, 1, K);                                                       \
+    if constexpr (TMW == 2) { rAh2 = HD_LD(pAh, 2, K); rAh3 = HD_LD(pAh, 3, K); }                           \
+    if constexpr (!PLAIN) {                                                                                 \
+        rAl0 = HD_LD(pAl, 0, K); rAl1 = HD_LD(pAl, 1, K);                                                   \
+        if constexpr (TMW == 2) { rAl2 = HD_LD(pAl, 2, K); rAl3 = HD_LD(pAl, 3, K); }                       \
+    }                                                                                                       \
     rG0 = HD_LG(0, K); rG1 = HD_LG(1, K); rG2 = HD_LG(2, K);                                                \
     if constexpr (!PLAIN) { rG3 = HD_LG(3, K); rG4 = HD_LG(4, K); }
 #define HD_STA(m, j, r) *reinterpret_cast<uint4*>(sA[m] + aloff + (j) * 32 * PA) = r
 #define HD_STG(j, r) *reinterpret_cast<uint4*>(lg##j) = r
-    f32x16 acc[2][NDX];
+    f32x16 acc[TMW][NDX];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < TMW; ++a)
 #pragma unroll
         for (int b = 0; b < NDX; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     HD_GLOAD(0)
     for (int s = 0; s < nslices; ++s) {
-        HD_STA(0, 0, rAh0); HD_STA(0, 1, rAh1); HD_STA(0, 2, rAh2); HD_STA(0, 3, rAh3);
-        if constexpr (!PLAIN) { HD_STA(1, 0, rAl0); HD_STA(1, 1, rAl1); HD_STA(1, 2, rAl2); HD_STA(1, 3, rAl3); }
+        HD_STA(0, 0, rAh0); HD_STA(0, 1, rAh1);
+        if constexpr (TMW == 2) { HD_STA(0, 2, rAh2); HD_STA(0, 3, rAh3); }
+        if constexpr (!PLAIN) {
+            HD_STA(1, 0, rAl0); HD_STA(1, 1, rAl1);
+            if constexpr (TMW == 2) { HD_STA(1, 2, rAl2); HD_STA(1, 3, rAl3); }
+        }
         HD_STG(0, rG0); HD_STG(1, rG1); HD_STG(2, rG2);          // chunks 0..767: all of hi (and, harmlessly, the first lo chunks)
         if constexpr (!PLAIN) { HD_STG(3, rG3); HD_STG(4, rG4); }
         __syncthreads();
         { const size_t kn = (size_t)min(s + 1, nslices - 1) * KS; HD_GLOAD(kn) }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 ah[2], al[2];
+            bf16x8 ah[TMW], al[TMW];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int ro = (wm * 64 + t * 32 + l31) * PA + ks * 32 + half * 16;
+            for (int t = 0; t < TMW; ++t) {
+                const int ro = (wm * 32 * TMW + t * 32 + l31) * PA + ks * 32 + half * 16;
                 ah[t] = *reinterpret_cast<const bf16x8*>(sA[0] + ro);
                 if constexpr (!PLAIN) al[t] = *reinterpret_cast<const bf16x8*>(sA[1] + ro);
             }
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
                 }
             }
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
+            for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
                 for (int dx = 0; dx < NDX; ++dx) {
                     if constexpr (!PLAIN) {
@@ -248,12 +257,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
 #undef HD_STG
     float* out = partial + ((size_t)(split * NDX + (ONE ? 0 : dyi)) * M) * N;
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TMW; ++tm)
 #pragma unroll
         for (int dx = 0; dx < NDX; ++dx)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * BM + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = mt * BM + wm * 32 * TMW + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int n = dx * F + nt * BN + wn * 32 + l31;
                 out[(size_t)m * N + n] = acc[tm][dx][r];
             }
@@ -605,7 +614,10 @@ struct Wgrad {
     // dW[Cout][Cin][KT][KT] (+)= scale * sum over pixels (activation image rows 0..Cin-1, gradient image rows 0..Cout-1)
     int run(int Cin, int Cout, int KT, float scale, bool accumulate, float* dW, bool plain, hipStream_t st) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
-        const int Mt = (Cin + 127) / 128, Nt = Cout / 64, Mpad = Mt * 128;
+        // layers with at most 64 input channels take the 64-row tile (no padded half); everything else 128 rows per workgroup
+        static const bool no64 = getenv("HICDIFF_WG_NO64") != nullptr;
+        const bool m64 = Cin <= 64 && !no64;
+        const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
         if (Cout % 64 || Mpad > maxCin || Cout > maxCout || (KT != 1 && KT != 3)) { hd_set_error("wgrad: unsupported shape"); return -1; }
         // splits of this call: enough workgroups for two per CU, within the partial buffer (sized for splitK splits of the widest layer)
         int eff = splitK;
@@ -619,8 +631,10 @@ struct Wgrad {
         hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, (plain ? 1.0 : 2.0) * 2 * (Cin + Cout) * (double)Kpad + 4.0 * eff * KT * KT * Cin * Cout, st);
         const dim3 grid(Mt * Nt * eff);
 #define HD_WG_LAUNCH(PLAIN_, ONE_)                                                                                          \
-        hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
-                           partial, xcd_group)
+        if (m64) hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 1>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
+                                    partial, xcd_group);                                                                    \
+        else hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 2>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
+                                partial, xcd_group)
         if (KT == 1) { if (plain) HD_WG_LAUNCH(true, true); else HD_WG_LAUNCH(false, true); }
         else { if (plain) HD_WG_LAUNCH(true, false); else HD_WG_LAUNCH(false, false); }
 #undef HD_WG_LAUNCH

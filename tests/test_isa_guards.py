@@ -58,9 +58,10 @@ def test_weight_gradient_gemm_keeps_its_prefetch_in_registers():
     (4.6x slower).  The GEMM's slice loop must have no scratch traffic and must issue its 13 loads of a slice back to back."""
     text = _asm("train.hip")
     kernels = dict(re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S))
-    # <PLAIN, ONE>: <false, false> = split-bf16 x3, three column taps (72 MFMAs and 13 loads per slice); <true, false> = plain bf16
-    # (24 MFMAs, 7 loads); <false, true> = 1x1 filter, split-bf16 x3 (24 MFMAs, 13 loads)
-    for tag, mfmas, loads in (("ILb0ELb0E", 72, 13), ("ILb1ELb0E", 24, 7), ("ILb0ELb1E", 24, 13)):
+    # <PLAIN, ONE, TMW>: <false, false, 2> = split-bf16 x3, three column taps, 128 input channels per workgroup (72 MFMAs and 13 loads per
+    # slice); <true, false, 2> = plain bf16 (24 MFMAs, 7 loads); <false, true, 2> = 1x1 filter, split-bf16 x3 (24 MFMAs, 13 loads);
+    # <false, false, 1> = the 64-input-channel tile (36 MFMAs, 9 loads)
+    for tag, mfmas, loads in (("ILb0ELb0ELi2E", 72, 13), ("ILb1ELb0ELi2E", 24, 7), ("ILb0ELb1ELi2E", 24, 13), ("ILb0ELb0ELi1E", 36, 9)):
         name = next(k for k in kernels if "wgrad_gemm_kernel" in k and tag in k)
         body = text[text.index(name + ":"):]
         body = body[:body.index("s_endpgm")]
