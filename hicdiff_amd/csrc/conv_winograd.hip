@@ -45,6 +45,11 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 #define ABL(bit) false
 #endif
 
+#ifdef HD_DIAG
+__device__ unsigned long long g_wino_stamps[2][8];   // [group][T part, M part, wait at B1, wait at Bmid, total loop, epilogue 1, epilogue 2, -]: cycles of workgroup 5, waves 0 / 4
+#define STAMP() __builtin_readcyclecounter()
+#endif
+
 namespace {
 
 constexpr int WIN = 18;                    // window side: 16 output pixels + halo
@@ -262,11 +267,21 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_bf16x3_kernel(ConvKArgs 
     float* const S = reinterpret_cast<float*>(smem);
     auto run = [&](auto first_is_t) {
         constexpr bool T_FIRST = decltype(first_is_t)::value;
+#ifdef HD_DIAG
+        unsigned long long cT = 0, cM = 0, cB1 = 0, cB2 = 0, t0, t1;
+        const unsigned long long tstart = STAMP();
+#endif
         for (int s = 0; s < ns; ++s) {
             const char* Vc = Vs + (s & 1) * VBUF;
             char* Vn = Vs + ((s + 1) & 1) * VBUF;
             const int sn = s + 1 < ns ? s + 1 : ns - 1;
+#ifdef HD_DIAG
+            t0 = STAMP();
+#endif
             __syncthreads();     // B1: V[s] complete; plane 0 holds window s+1; plane 1's readers are done
+#ifdef HD_DIAG
+            t1 = STAMP(); cB1 += t1 - t0;
+#endif
             if constexpr (T_FIRST) {
                 t_part(Vn);
                 HD_WLOAD(2, s) HD_WLOAD(3, s)
@@ -275,7 +290,13 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_bf16x3_kernel(ConvKArgs 
                 a_request(s + 2);
                 HD_MSTAGE(Vc, sn)
             }
+#ifdef HD_DIAG
+            t0 = STAMP(); if (T_FIRST) cT += t0 - t1; else cM += t0 - t1;
+#endif
             __syncthreads();     // Bmid: plane 0's readers are done; plane 1 holds window s+1
+#ifdef HD_DIAG
+            t1 = STAMP(); cB2 += t1 - t0;
+#endif
             if constexpr (T_FIRST) {
                 a_store();                             // plane 0 of window s+2
                 a_request(s + 3);
@@ -284,21 +305,33 @@ __global__ __launch_bounds__(512, 2) void conv_winograd_bf16x3_kernel(ConvKArgs 
                 t_part(Vn);
                 HD_WLOAD(2, sn) HD_WLOAD(3, sn)
             }
+#ifdef HD_DIAG
+            t0 = STAMP(); if (T_FIRST) cM += t0 - t1; else cT += t0 - t1;
+#endif
         }
         __syncthreads();                               // all MFMA operand reads done: V becomes the exchange buffer
+#ifdef HD_DIAG
+        const unsigned long long tloop = STAMP();
+#endif
         // ---- epilogue 1: output transform along j in registers, T[b] -> S[i][b][tile][channel]
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) {
-            const f32x16 t0 = acc[0][mb] + acc[1][mb] + acc[2][mb];
-            const f32x16 t1 = acc[1][mb] - acc[2][mb] - acc[3][mb];
+            const f32x16 t0v = acc[0][mb] + acc[1][mb] + acc[2][mb];
+            const f32x16 t1v = acc[1][mb] - acc[2][mb] - acc[3][mb];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int tile = mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int col = nb * 32 + l31;
-                S[((wi * 2 + 0) * 64 + tile) * 64 + col] = t0[r];
-                S[((wi * 2 + 1) * 64 + tile) * 64 + col] = t1[r];
+                S[((wi * 2 + 0) * 64 + tile) * 64 + col] = t0v[r];
+                S[((wi * 2 + 1) * 64 + tile) * 64 + col] = t1v[r];
             }
         }
+#ifdef HD_DIAG
+        if (blockIdx.x == 5 && (tid & 255) == 0) {
+            unsigned long long* g = g_wino_stamps[T_FIRST ? 0 : 1];
+            g[0] = cT; g[1] = cM; g[2] = cB1; g[3] = cB2; g[4] = tloop - tstart; g[5] = STAMP() - tloop;
+        }
+#endif
     };
     if (grp == 0) run(std::true_type{}); else run(std::false_type{});
 #undef HD_MSTAGE
@@ -460,3 +493,9 @@ int launch_conv_winograd(ConvLaunch& L, hipStream_t st) {
     HD_W(2, 1);
 #undef HD_W
 }
+
+#ifdef HD_DIAG
+extern "C" int hd_debug_wino_stamps(unsigned long long* out16) {
+    return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wino_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -3;
+}
+#endif

@@ -144,8 +144,8 @@ template <bool PLAIN, bool ONE, int TMW = 2>      // PLAIN: hi x hi only -- no l
 // TMW: 32-row blocks per wave: 2 = 128 input channels per workgroup, 1 = 64 (layers with 64 input channels: no padded half)
 __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short* __restrict__ Ahi, const unsigned short* __restrict__ Alo,
                                                             const unsigned short* __restrict__ Ghi, const unsigned short* __restrict__ Glo,
-                                                            size_t ld, size_t guard, int P, size_t kchunk, int nsplit, int Mtiles, int Ntiles, int M, int F,
-                                                            float* __restrict__ partial, int xcd_group) {
+                                                            size_t ld, size_t guard, int P, int slices_per_split, int total_slices, int nsplit, int Mtiles,
+                                                            int Ntiles, int M, int F, float* __restrict__ partial, int xcd_group) {
     constexpr int BM = 64 * TMW, BN = 64, KS = 64, PA = KS * 2 + 16, PG = (KS + 16) * 2 + 16;      // 144, 176 bytes
     __shared__ __attribute__((aligned(16))) char sA[2][BM * PA];
     __shared__ __attribute__((aligned(16))) char sG[2][BN * PG];
@@ -156,8 +156,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     if ((nsplit & 7) == 0 && xcd_group) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
     else { split = blockIdx.x / per; inner = blockIdx.x % per; }
     const int nt = inner % Ntiles, mt = inner / Ntiles;
-    const size_t k0 = guard + (size_t)split * kchunk;
-    const int nslices = (int)(kchunk / KS);
+    // this split's k range: slices_per_split slices of 64, the last split takes what is left (at least one: the host sizes nsplit so)
+    const size_t k0 = guard + (size_t)split * slices_per_split * KS;
+    const int nslices = min(slices_per_split, total_slices - split * slices_per_split);
     constexpr int NDX = ONE ? 1 : 3;
     const int N = NDX * F;
     // A: rows lrow + 32 j (j < 4), chunk lch.  G: 64 rows x 10 chunks x {hi, lo} = 1280 chunks, five per thread.
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     char* const lg##j = sG[wh##j] + row##j * PG + ch##j * 16;
     HD_GDEF(0) HD_GDEF(1) HD_GDEF(2) HD_GDEF(3) HD_GDEF(4)
 #undef HD_GDEF
-    for (int dyi = ONE ? 1 : 0; dyi < (ONE ? 2 : 3); ++dyi) {
+    // the three row taps are three workgroups (blockIdx.y): same XCD when gridDim.x is a multiple of 8, so they share the operand slices in L2
+    const int dyi = ONE ? 1 : (int)blockIdx.y;
+    {
     const size_t ka = (size_t)((long)k0 + (long)(dyi - 1) * P);
     const unsigned short* pAh = Ahi + (size_t)mt * BM * ld + ka + aoff;
     const unsigned short* pAl = Alo + (size_t)mt * BM * ld + ka + aoff;
@@ -563,9 +566,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // (B, H, W), because the zero padding of its operand images is positional.  rewrite() fills the activation image (gside == false;
 // channel-concatenated inputs are two calls with row0 = 0 and row0 = C0) or the gradient image; run() multiplies and reduces.
 struct Wgrad {
-    int B = 0, H = 0, W = 0, P = 0, splitK = 1, maxCin = 0, maxCout = 0;
+    int B = 0, H = 0, W = 0, P = 0, maxCin = 0, maxCout = 0;
     bool narrow = false;
-    size_t Kpad = 0, guard = 0, ld = 0, kchunk = 0;
+    size_t Kpad = 0, guard = 0, ld = 0, partial_floats = 0;
     unsigned short *a_hi = nullptr, *a_lo = nullptr, *b_hi = nullptr, *b_lo = nullptr;
     float* partial = nullptr;
     std::vector<void*> owned;
@@ -574,15 +577,8 @@ struct Wgrad {
         B = B_; H = H_; W = W_; maxCin = (maxCin_ + 127) / 128 * 128; maxCout = maxCout_;
         P = ((W + 7) & ~7) + 8;
         const size_t K = ((size_t)B * (H + 1) + 1) * P;
-        // 8 tiles of 128 x 64 (x 3 taps) per split at 256 channels; 64 splits = 512 workgroups = one round at two per CU, 8 splits per XCD
-        const size_t max_split = getenv("HICDIFF_WG_SPLITK") ? (size_t)atoi(getenv("HICDIFF_WG_SPLITK")) : 64;
-        splitK = (int)std::max<size_t>(1, std::min<size_t>(max_split, K / 2048));
-        if (splitK >= 8) splitK &= ~7;
-        // narrow layers (one or two tiles per split) take more splits at run time (up to 4x): keep every such chunk a whole number of slices
-        const size_t quantum = (size_t)64 * splitK * (narrow_layers && splitK >= 64 ? 4 : 1);
         narrow = narrow_layers;
-        Kpad = (K + quantum - 1) / quantum * quantum;
-        kchunk = Kpad / splitK;
+        Kpad = (K + 63) / 64 * 64;                                // whole slices of 64; run() cuts it into splits
         guard = ((size_t)P + 72 + 63) / 64 * 64;                  // row shift (P) + one slice of read-ahead
         ld = guard + Kpad + guard;
         auto zalloc = [&](size_t bytes) -> void* {
@@ -594,7 +590,9 @@ struct Wgrad {
         };
         a_hi = (unsigned short*)zalloc((size_t)maxCin * ld * 2); a_lo = (unsigned short*)zalloc((size_t)maxCin * ld * 2);
         b_hi = (unsigned short*)zalloc((size_t)maxCout * ld * 2); b_lo = (unsigned short*)zalloc((size_t)maxCout * ld * 2);
-        partial = (float*)zalloc((size_t)splitK * 9 * maxCin * maxCout * sizeof(float));
+        // room for the split-k partials: 8 splits of the widest layer, and at least 128 MiB so that the narrow layers can be cut finely
+        partial_floats = std::max<size_t>((size_t)8 * 9 * maxCin * maxCout, (size_t)32 << 20);
+        partial = (float*)zalloc(partial_floats * sizeof(float));
         return a_hi && a_lo && b_hi && b_lo && partial;
     }
     int rewrite(const float* in, int C, int row0, bool gside, int mode, const float* film, int film_bs, const float* affB, float* colpart, bool plain,
@@ -619,21 +617,32 @@ struct Wgrad {
         const bool m64 = Cin <= 64 && !no64;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
         if (Cout % 64 || Mpad > maxCin || Cout > maxCout || (KT != 1 && KT != 3)) { hd_set_error("wgrad: unsupported shape"); return -1; }
-        // splits of this call: enough workgroups for two per CU, within the partial buffer (sized for splitK splits of the widest layer)
-        int eff = splitK;
-        if (narrow && splitK >= 64)
-            while (eff < 4 * splitK && Mt * Nt * eff < 512 && (size_t)(2 * eff) * KT * KT * Mpad * Cout <= (size_t)splitK * 9 * maxCin * maxCout) eff *= 2;
-        const size_t kch = Kpad / eff;
+        // splits of this call: the three row taps are separate workgroups, and k is cut until ~two rounds of workgroups exist (two
+        // fit a CU), each keeping at least 8 slices of 64 and the partials fitting their buffer.  (Round 1 cut k only 40 / 8 / 4 ways on
+        // the 32x32 / 16x16 / 8x8 maps: 64-128 workgroups on 256 CUs, each looping over the three row taps.)
+        // Measured (MI355X, 64 tiles): the UNet's layers (1-12 tiles per split) are fastest with ONE round of 512 workgroups (39.0 ms per
+        // step; 40.7-40.8 at 256 / 768 / 1024), hicedrn's 24-tile layers with 960 (0.96 ms per GEMM; 1.02 at 384).
+        static const int target_env = getenv("HICDIFF_WG_TARGET") ? atoi(getenv("HICDIFF_WG_TARGET")) : 0;
+        const int ndy = KT == 3 ? 3 : 1, total = (int)(Kpad / 64);
+        const int target = target_env ? target_env : (Mt * Nt * ndy >= 16 ? 1024 : 512);
+        const size_t per_split_floats = (size_t)KT * KT * Mpad * Cout;
+        int eff = std::max(1, target / (Mt * Nt * ndy));
+        eff = std::min<int>(eff, std::max(1, total / 8));
+        eff = (int)std::min<size_t>((size_t)eff, partial_floats / per_split_floats);
+        if (eff >= 8) eff &= ~7;
+        eff = std::max(eff, 1);
+        const int sps = (total + eff - 1) / eff;
+        eff = (total + sps - 1) / sps;                      // no empty split
         // algorithmic figures: KT*KT taps x Cin x Cout outputs over the B*H*W real pixels (3 MFMA flops per product are the kernel's business);
         // bytes: both operand images once (hi + lo) + the partials
         const char* name = KT == 1 ? (plain ? "wgrad_gemm_kernel<true, true>" : "wgrad_gemm_kernel<false, true>")
                                    : (plain ? "wgrad_gemm_kernel<true>" : "wgrad_gemm_kernel<false>");
         hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, (plain ? 1.0 : 2.0) * 2 * (Cin + Cout) * (double)Kpad + 4.0 * eff * KT * KT * Cin * Cout, st);
-        const dim3 grid(Mt * Nt * eff);
+        const dim3 grid(Mt * Nt * eff, ndy);
 #define HD_WG_LAUNCH(PLAIN_, ONE_)                                                                                          \
-        if (m64) hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 1>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
+        if (m64) hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 1>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, sps, total, eff, Mt, Nt, Mpad, Cout, \
                                     partial, xcd_group);                                                                    \
-        else hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 2>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, kch, eff, Mt, Nt, Mpad, Cout, \
+        else hipLaunchKernelGGL((wgrad_gemm_kernel<PLAIN_, ONE_, 2>), grid, dim3(256), 0, st, a_hi, a_lo, b_hi, b_lo, ld, guard, P, sps, total, eff, Mt, Nt, Mpad, Cout, \
                                 partial, xcd_group)
         if (KT == 1) { if (plain) HD_WG_LAUNCH(true, true); else HD_WG_LAUNCH(false, true); }
         else { if (plain) HD_WG_LAUNCH(true, false); else HD_WG_LAUNCH(false, false); }

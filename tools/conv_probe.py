@@ -54,6 +54,12 @@ def main():
         print(f"{r.kernel.decode():50s} {us:9.1f} us  {r.flops / r.total_ms / 1e9:7.1f} TFLOP/s-eq  {r.bytes / r.total_ms / 1e6:6.0f} GB/s  "
               f"[B={a.B} S={a.S} {a.cin}->{a.cout} mode={mode} ablate={os.environ.get('HICDIFF_ABLATE', '0')}]")
     lib.hd_profile_enable(0)
+    if hasattr(lib, "hd_debug_wino_stamps"):           # DIAG builds: in-kernel cycle stamps of one workgroup (conv_winograd.hip)
+        buf = (C.c_ulonglong * 16)()
+        if lib.hd_debug_wino_stamps(buf) == 0:
+            for g in range(2):
+                v = [buf[g * 8 + i] for i in range(6)]
+                print(f"  stamps group {g}: T part {v[0]}  M part {v[1]}  wait B1 {v[2]}  wait Bmid {v[3]}  loop {v[4]}  epilogue-1 {v[5]}  (cycles, one wave)")
 
 
 if __name__ == "__main__":
