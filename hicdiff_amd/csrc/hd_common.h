@@ -138,10 +138,11 @@ int launch_tile_metrics(const float* pred, const float* target, int B, int S, in
                         hipStream_t st);
 // training components (train_norms.hip)
 size_t gn_bwd_scratch_floats(int B, int HW, int C);
-int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta, const float* film,
-                       int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta, float* dfilm,
-                       int accumulate, hipStream_t st, int dfilm_bs = 0);
-int launch_ln_bwd(const float* x, float* dy, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
+// g -> gout / dy -> dout: the output may be the input buffer (in place) or another one
+int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta,
+                       const float* film, int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta,
+                       float* dfilm, int accumulate, hipStream_t st, int dfilm_bs = 0);
+int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
 int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st);
 int launch_ws_fwd(const float* w, int Cout, int n, float* out, hipStream_t st);
 int launch_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, hipStream_t st);   // train_attn.hip

@@ -43,22 +43,35 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     }
 }
 
-// One workgroup per sample.  T: [B][2][C] (chunks already summed).  film: [B][film_bs] with scale at film_off + c and shift at
+// One workgroup per sample.  part: [B][nchunk][2][C] per-chunk sums, added here in col_sum_kernel's order (eight chains).  film: [B][film_bs] with scale at film_off + c and shift at
 // film_off + C + c (film_mode 1), or nothing (0).  Writes coef[b][c] = {rstd w, rstd M1_g, rstd M2_g, -} for the apply pass,
 // dfilm[b][2C] = (d scale, d shift) and U[b][2][C] = ((1+s) T2, (1+s) T1) whose sums over b are d gamma, d beta.
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ T, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const float* __restrict__ film, int film_bs, int film_off,
-                                                              int film_mode, int HW, int C, int G, float4* __restrict__ coef, float* __restrict__ dfilm,
-                                                              float* __restrict__ U, int dfilm_bs) {
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int nchunk, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ film,
+                                                              int film_bs, int film_off, int film_mode, int HW, int C, int G, float4* __restrict__ coef,
+                                                              float* __restrict__ dfilm, float* __restrict__ U, int dfilm_bs) {
+    extern __shared__ float Tsh[];                           // [2][C]: sum dv, sum dv * xhat of this sample
     __shared__ float m1[64], m2[64];
     const int b = blockIdx.x, cg = C / G;
+    for (int col = threadIdx.x; col < 2 * C; col += 256) {
+        const float* in = part + (size_t)b * nchunk * 2 * C + col;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int r = 0;
+        for (; r + 8 <= nchunk; r += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += in[(size_t)(r + j) * 2 * C];
+        }
+        for (; r < nchunk; ++r) a[r & 7] += in[(size_t)r * 2 * C];
+        Tsh[col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
+    __syncthreads();
     if (threadIdx.x < G) {                                   // one thread per group walks its channels in order
         const int g0 = threadIdx.x * cg;
         float s1 = 0.f, s2 = 0.f;
         for (int j = 0; j < cg; ++j) {
             const int c = g0 + j;
             const float w = gamma[c] * (film_mode == 1 ? film[(size_t)b * film_bs + film_off + c] + 1.f : 1.f);
-            s1 += w * T[((size_t)b * 2) * C + c]; s2 += w * T[((size_t)b * 2 + 1) * C + c];
+            s1 += w * Tsh[c]; s2 += w * Tsh[C + c];
         }
         const float n = (float)HW * cg;
         m1[threadIdx.x] = s1 / n; m2[threadIdx.x] = s2 / n;
@@ -68,15 +81,15 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
         const int gi = c / cg;
         const float rs = stats[((size_t)b * G + gi) * 2 + 1];
         const float sc1 = film_mode == 1 ? film[(size_t)b * film_bs + film_off + c] + 1.f : 1.f;
-        const float t1 = T[((size_t)b * 2) * C + c], t2 = T[((size_t)b * 2 + 1) * C + c];
+        const float t1 = Tsh[c], t2 = Tsh[C + c];
         coef[(size_t)b * C + c] = make_float4(rs * gamma[c] * sc1, rs * m1[gi], rs * m2[gi], 0.f);
         if (dfilm && film_mode == 1) { dfilm[(size_t)b * dfilm_bs + c] = gamma[c] * t2 + beta[c] * t1; dfilm[(size_t)b * dfilm_bs + C + c] = t1; }
         U[((size_t)b * 2) * C + c] = sc1 * t2; U[((size_t)b * 2 + 1) * C + c] = sc1 * t1;
     }
 }
 
-// g <- dL/dx = rstd (dv w - M1 - xhat M2), in place
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, float* __restrict__ g, const float* __restrict__ A,
+// gout <- dL/dx = rstd (dv w - M1 - xhat M2); gout may be g
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* g, float* gout, const float* __restrict__ A,
                                                            const float* __restrict__ Bv, const float* __restrict__ stats, const float4* __restrict__ coef,
                                                            int HW, int C, int G, size_t n) {
     const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     const float dv = g[e] * dsilu_f(xv * A[(size_t)b * C + c] + Bv[(size_t)b * C + c]);
     const float mu = stats[((size_t)b * G + c / cg) * 2], rs = stats[((size_t)b * G + c / cg) * 2 + 1];
     const float4 k = coef[(size_t)b * C + c];
-    g[e] = dv * k.x - k.y - (xv - mu) * rs * k.z;
+    gout[e] = dv * k.x - k.y - (xv - mu) * rs * k.z;
 }
 
 // out[col] (+)= sum_row in[row][col], eight independent chains; grid.y batches (in and out advance by nrows*ncols and ncols)
@@ -105,10 +118,27 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
     out[col] = (accumulate ? out[col] : 0.f) + s;
 }
 
+// dgamma[c] (+)= sum_b U[b][0][c], dbeta[c] (+)= sum_b U[b][1][c]  (col_sum_kernel's order over b)
+__global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ U, int Bn, int C, int accumulate, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= 2 * C) return;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 8 <= Bn; r += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += U[(size_t)(r + j) * 2 * C + col];
+    }
+    for (; r < Bn; ++r) a[r & 7] += U[(size_t)r * 2 * C + col];
+    const float s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    float* out = col < C ? dgamma + col : dbeta + (col - C);
+    *out = (accumulate ? *out : 0.f) + s;
+}
+
 // ---- channel LayerNorm (gain only) ---------------------------------------------------------------------------------------
-// y = (x - mean_c) rstd g.  One wave per pixel row: dx = rstd (dy g - mean_c(dy g) - xhat mean_c(dy g xhat)), in place over dy;
+// y = (x - mean_c) rstd g.  One wave per pixel row: dx = rstd (dy g - mean_c(dy g) - xhat mean_c(dy g xhat)) written to dout (may be dy);
 // part[blockIdx][C]: this workgroup's sum over its rows of dy * xhat (d gain), reduced afterwards.
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, float* __restrict__ dy, const float* __restrict__ gain, size_t P, int C,
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* dy, float* dout, const float* __restrict__ gain, size_t P, int C,
                                                      int rows_per_block, float* __restrict__ part) {
     extern __shared__ float dg[];                           // [4 waves][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -119,7 +149,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         const size_t r = r0 + rr;
         if (r >= P) break;
         const float* xr = x + r * C;
-        float* dr = dy + r * C;
+        const float* dr = dy + r * C;
+        float* dw = dout + r * C;
         float s = 0.f;
         for (int c = lane; c < C; c += 64) s += xr[c];
 #pragma unroll
@@ -139,7 +170,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
         s1 /= C; s2 /= C;
-        for (int c = lane; c < C; c += 64) dr[c] = rs * (dr[c] * gain[c] - s1 - (xr[c] - mean) * rs * s2);
+        for (int c = lane; c < C; c += 64) dw[c] = rs * (dr[c] * gain[c] - s1 - (xr[c] - mean) * rs * s2);
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = (dg[c] + dg[C + c]) + (dg[2 * C + c] + dg[3 * C + c]);
@@ -207,33 +238,28 @@ int launch_ws_fwd(const float* w, int Cout, int n, float* out, hipStream_t st) {
 // scratch: B * nchunk * 2C (partials) + B * 2C (T) + B * 2C (U) + B * C * 4 (coef) floats, nchunk = ceil(HW / 64)
 size_t gn_bwd_scratch_floats(int B, int HW, int C) { return (size_t)B * ((HW + 63) / 64) * 2 * C + (size_t)B * 2 * C * 2 + (size_t)B * C * 4; }
 
-int launch_gn_silu_bwd(const float* x, float* g, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta, const float* film,
-                       int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta, float* dfilm,
-                       int accumulate, hipStream_t st, int dfilm_bs) {
+int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta,
+                       const float* film, int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta,
+                       float* dfilm, int accumulate, hipStream_t st, int dfilm_bs) {
     if (dfilm_bs <= 0) dfilm_bs = 2 * C;                       // dfilm rows: (d scale | d shift) at dfilm + b * dfilm_bs
     if (C % G || G > 64 || (film_mode != 0 && film_mode != 1)) { hd_set_error("gn backward: unsupported shape"); return -1; }
     const int nchunk = (HW + 63) / 64;
     float* part = scratch;
-    float* T = part + (size_t)B * nchunk * 2 * C;
-    float* U = T + (size_t)B * 2 * C;
+    float* U = part + (size_t)B * nchunk * 2 * C + (size_t)B * 2 * C;
     float4* coef = reinterpret_cast<float4*>(U + (size_t)B * 2 * C);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, g, A, Bv, stats, HW, C, G, 64, part);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, st, part, nchunk, 2 * C, 0, T);      // T[b] = sum over the sample's chunks
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), 0, st, T, stats, gamma, beta, film, film_bs, film_off, film_mode, HW, C, G, coef, dfilm, U, dfilm_bs);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(B), dim3(256), (size_t)2 * C * sizeof(float), st, part, nchunk, stats, gamma, beta, film, film_bs, film_off,
+                       film_mode, HW, C, G, coef, dfilm, U, dfilm_bs);
     const size_t n = (size_t)B * HW * C;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, g, A, Bv, stats, coef, HW, C, G, n);
-    // d gamma = sum_b U[b][0], d beta = sum_b U[b][1]: U viewed as [B rows][2C cols]
-    float* two = T;                                          // T is free again: [2C] = (d gamma | d beta)
-    hipLaunchKernelGGL(col_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, U, B, 2 * C, 0, two);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, two, 1, C, accumulate, dgamma);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, two + C, 1, C, accumulate, dbeta);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, g, gout, A, Bv, stats, coef, HW, C, G, n);
+    hipLaunchKernelGGL(gn_param_grads_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, st, U, B, C, accumulate, dgamma, dbeta);
     return check_launch("gn backward");
 }
 
-int launch_ln_bwd(const float* x, float* dy, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st) {
+int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st) {
     const int rows = 64;
     const unsigned nb = (unsigned)((P + rows - 1) / rows);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, gain, P, C, rows, scratch);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, dout, gain, P, C, rows, scratch);
     hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, (int)nb, C, accumulate, dgain);
     return check_launch("ln backward");
 }
@@ -260,7 +286,7 @@ int hd_debug_gn_silu_bwd(const float* x, float* g, const float* gamma, const flo
     int rc = ok ? 0 : -4;
     if (!rc) rc = launch_gn_partial(x, B, HW, C, part, &slots, st);
     if (!rc) rc = launch_gn_finalize(part, slots, B, HW, C, G, gamma, beta, film, 2 * C, 0, film ? 1 : 0, A, Bv, nullptr, st, stats);
-    if (!rc) rc = launch_gn_silu_bwd(x, g, A, Bv, stats, gamma, beta, film, 2 * C, 0, film ? 1 : 0, B, HW, C, G, scratch, dgamma, dbeta, dfilm, 0, st, 0);
+    if (!rc) rc = launch_gn_silu_bwd(x, g, g, A, Bv, stats, gamma, beta, film, 2 * C, 0, film ? 1 : 0, B, HW, C, G, scratch, dgamma, dbeta, dfilm, 0, st, 0);
     (void)hipStreamSynchronize(st);
     for (float* p : {part, A, Bv, stats, scratch}) if (p) (void)hipFree(p);
     return rc ? (rc == -4 ? HD_ENOMEM : HD_EHIP) : HD_OK;
@@ -271,7 +297,7 @@ int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, i
     hipStream_t st = (hipStream_t)stream;
     float* scratch = nullptr;
     if (hipMalloc(&scratch, ((size_t)(P + 63) / 64) * C * sizeof(float)) != hipSuccess) return HD_ENOMEM;
-    const int rc = launch_ln_bwd(x, dy, gain, (size_t)P, C, scratch, dgain, 0, st);
+    const int rc = launch_ln_bwd(x, dy, dy, gain, (size_t)P, C, scratch, dgain, 0, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(scratch);
     return rc ? HD_EHIP : HD_OK;
