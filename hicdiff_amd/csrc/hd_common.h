@@ -142,6 +142,7 @@ size_t gn_bwd_scratch_floats(int B, int HW, int C);
 int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float* A, const float* Bv, const float* stats, const float* gamma, const float* beta,
                        const float* film, int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta,
                        float* dfilm, int accumulate, hipStream_t st, int dfilm_bs = 0);
+size_t ln_bwd_scratch_floats(size_t P, int C);
 int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
 int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st);
 int launch_ws_fwd(const float* w, int Cout, int n, float* out, hipStream_t st);

@@ -26,9 +26,40 @@ int check_launch(const char* what) {
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ A,
                                                              const float* __restrict__ Bv, const float* __restrict__ stats, int HW, int C, int G,
                                                              int chunk, float* __restrict__ part) {
+    // thread = (channel quad, pixel group): float4 accesses and all 256 threads busy at every width (one thread per channel left three
+    // quarters of the workgroup idle at C = 64); the pixel groups' sums meet in LDS and are added in order
+    __shared__ float red[2 * 1024];                         // [pixel group][2][C], npg * C = 1024
     const int b = blockIdx.y, ck = blockIdx.x, nchunk = gridDim.x, cg = C / G;
     const int p0 = ck * chunk, p1 = min(HW, p0 + chunk);
-    for (int c = threadIdx.x; c < C; c += 256) {
+    const int nq = C >> 2;
+    if (nq <= 256 && (C & 3) == 0 && (cg & 3) == 0) {
+        const int npg = 256 / nq, q = threadIdx.x % nq, pg = threadIdx.x / nq, c = q * 4;
+        if (pg < npg) {
+            const float4 a = *reinterpret_cast<const float4*>(A + (size_t)b * C + c), bb = *reinterpret_cast<const float4*>(Bv + (size_t)b * C + c);
+            const float mu = stats[((size_t)b * G + c / cg) * 2], rs = stats[((size_t)b * G + c / cg) * 2 + 1];     // cg % 4 == 0: one group per quad
+            float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+            for (int p = p0 + pg; p < p1; p += npg) {
+                const size_t e = ((size_t)b * HW + p) * C + c;
+                const float4 xv = *reinterpret_cast<const float4*>(x + e), gv = *reinterpret_cast<const float4*>(g + e);
+                float dv;
+                dv = gv.x * dsilu_f(xv.x * a.x + bb.x); t1.x += dv; t2.x += dv * (xv.x - mu) * rs;
+                dv = gv.y * dsilu_f(xv.y * a.y + bb.y); t1.y += dv; t2.y += dv * (xv.y - mu) * rs;
+                dv = gv.z * dsilu_f(xv.z * a.z + bb.z); t1.z += dv; t2.z += dv * (xv.z - mu) * rs;
+                dv = gv.w * dsilu_f(xv.w * a.w + bb.w); t1.w += dv; t2.w += dv * (xv.w - mu) * rs;
+            }
+            *reinterpret_cast<float4*>(red + (size_t)pg * 2 * C + c) = t1;
+            *reinterpret_cast<float4*>(red + (size_t)pg * 2 * C + C + c) = t2;
+        }
+        __syncthreads();
+        float* d = part + (size_t)(b * nchunk + ck) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            float t = 0.f;
+            for (int k = 0; k < npg; ++k) t += red[(size_t)k * 2 * C + i];
+            d[i] = t;
+        }
+        return;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) {            // wider than 1024 channels: one thread per channel
         const float a = A[(size_t)b * C + c], bb = Bv[(size_t)b * C + c];
         const float mu = stats[((size_t)b * G + c / cg) * 2], rs = stats[((size_t)b * G + c / cg) * 2 + 1];
         float t1 = 0.f, t2 = 0.f;
@@ -118,6 +149,21 @@ __global__ __launch_bounds__(256) void col_sum_kernel(const float* __restrict__ 
     out[col] = (accumulate ? out[col] : 0.f) + s;
 }
 
+// out[g][col] = sum of rows g*per .. min(nrows, (g+1)*per) - 1 of in[row][col]  (first level of a long column sum)
+__global__ __launch_bounds__(256) void col_sum_groups_kernel(const float* __restrict__ in, int nrows, int per, int ncols, float* __restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+    if (col >= ncols) return;
+    const int r0 = g * per, r1 = min(nrows, r0 + per);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] += in[(size_t)(r + j) * ncols + col];
+    }
+    for (; r < r1; ++r) a[0] += in[(size_t)r * ncols + col];
+    out[(size_t)g * ncols + col] = (a[0] + a[1]) + (a[2] + a[3]);
+}
+
 // dgamma[c] (+)= sum_b U[b][0][c], dbeta[c] (+)= sum_b U[b][1][c]  (col_sum_kernel's order over b)
 __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __restrict__ U, int Bn, int C, int accumulate, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta) {
@@ -136,44 +182,73 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __rest
 }
 
 // ---- channel LayerNorm (gain only) ---------------------------------------------------------------------------------------
-// y = (x - mean_c) rstd g.  One wave per pixel row: dx = rstd (dy g - mean_c(dy g) - xhat mean_c(dy g xhat)) written to dout (may be dy);
-// part[blockIdx][C]: this workgroup's sum over its rows of dy * xhat (d gain), reduced afterwards.
+// y = (x - mean_c) rstd g;  dx = rstd (dy g - mean_c(dy g) - xhat mean_c(dy g xhat)) written to dout (may be dy).
+// A row's C channels are spread over LPR = min(64, C / 4) lanes, a float4 (two when C = 512) per lane: a wave works on 64 / LPR rows at
+// once (four at C = 64; round 1's one-row-per-wave, one-channel-per-lane form ran at a third of the memory rate there).  Each lane
+// keeps its channels' d gain sums in registers; lanes, waves and then workgroups (part[blockIdx][C], col_sum afterwards) are combined
+// in a fixed order.  NV = float4s per lane.
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* dy, float* dout, const float* __restrict__ gain, size_t P, int C,
                                                      int rows_per_block, float* __restrict__ part) {
-    extern __shared__ float dg[];                           // [4 waves][C]
+    extern __shared__ float dg[];                           // [4 waves][64 / LPR rows][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    float* mine = dg + (size_t)w * C;
-    for (int c = lane; c < C; c += 64) mine[c] = 0.f;
+    const int lpr = C / (4 * NV), rpw = 64 / lpr;          // lanes per row, rows per wave
+    const int sub = lane % lpr, rw = lane / lpr;
+    float4 gq[NV], acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { gq[v] = *reinterpret_cast<const float4*>(gain + (sub + v * lpr) * 4); acc[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
     const size_t r0 = (size_t)blockIdx.x * rows_per_block;
-    for (int rr = w; rr < rows_per_block; rr += 4) {
+    const float invC = 1.f / C;
+    for (int rr = w * rpw + rw; rr < rows_per_block; rr += 4 * rpw) {
         const size_t r = r0 + rr;
-        if (r >= P) break;
-        const float* xr = x + r * C;
-        const float* dr = dy + r * C;
-        float* dw = dout + r * C;
+        const bool live = r < P;                              // whole-wave shuffles below: dead rows compute on zeros and store nothing
+        float4 xv[NV], dv[NV];
         float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += xr[c];
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-        const float mean = s / C;
-        float q = 0.f;
-        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
-        const float rs = 1.f / sqrtf(q / C + 1e-5f);
-        float s1 = 0.f, s2 = 0.f;
-        for (int c = lane; c < C; c += 64) {
-            const float xh = (xr[c] - mean) * rs, d = dr[c] * gain[c];
-            s1 += d; s2 += d * xh;
-            mine[c] += dr[c] * xh;
+        for (int v = 0; v < NV; ++v) {
+            xv[v] = live ? *reinterpret_cast<const float4*>(x + r * C + (sub + v * lpr) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            dv[v] = live ? *reinterpret_cast<const float4*>(dy + r * C + (sub + v * lpr) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (xv[v].x + xv[v].y) + (xv[v].z + xv[v].w);
         }
+        for (int m = lpr >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float mean = s * invC;
+        float q = 0.f;
 #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
-        s1 /= C; s2 /= C;
-        for (int c = lane; c < C; c += 64) dw[c] = rs * (dr[c] * gain[c] - s1 - (xr[c] - mean) * rs * s2);
+        for (int v = 0; v < NV; ++v) {
+            xv[v].x -= mean; xv[v].y -= mean; xv[v].z -= mean; xv[v].w -= mean;
+            q += (xv[v].x * xv[v].x + xv[v].y * xv[v].y) + (xv[v].z * xv[v].z + xv[v].w * xv[v].w);
+        }
+        for (int m = lpr >> 1; m >= 1; m >>= 1) q += __shfl_xor(q, m, 64);
+        const float rs = 1.f / sqrtf(q * invC + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            xv[v].x *= rs; xv[v].y *= rs; xv[v].z *= rs; xv[v].w *= rs;                 // xhat
+            acc[v].x += dv[v].x * xv[v].x; acc[v].y += dv[v].y * xv[v].y; acc[v].z += dv[v].z * xv[v].z; acc[v].w += dv[v].w * xv[v].w;
+            dv[v].x *= gq[v].x; dv[v].y *= gq[v].y; dv[v].z *= gq[v].z; dv[v].w *= gq[v].w;   // dy g
+            s1 += (dv[v].x + dv[v].y) + (dv[v].z + dv[v].w);
+            s2 += (dv[v].x * xv[v].x + dv[v].y * xv[v].y) + (dv[v].z * xv[v].z + dv[v].w * xv[v].w);
+        }
+        for (int m = lpr >> 1; m >= 1; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+        s1 *= invC; s2 *= invC;
+        if (live) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const float4 o = make_float4(rs * (dv[v].x - s1 - xv[v].x * s2), rs * (dv[v].y - s1 - xv[v].y * s2), rs * (dv[v].z - s1 - xv[v].z * s2),
+                                             rs * (dv[v].w - s1 - xv[v].w * s2));
+                *reinterpret_cast<float4*>(dout + r * C + (sub + v * lpr) * 4) = o;
+            }
+        }
     }
+    // d gain: [wave][row slot][C] in LDS, then one thread per channel adds the 4 * rpw slots in order
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4*>(dg + ((size_t)(w * rpw + rw) * C) + (sub + v * lpr) * 4) = acc[v];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) part[(size_t)blockIdx.x * C + c] = (dg[c] + dg[C + c]) + (dg[2 * C + c] + dg[3 * C + c]);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < 4 * rpw; ++k) t += dg[(size_t)k * C + c];
+        part[(size_t)blockIdx.x * C + c] = t;
+    }
 }
 
 // ---- weight standardisation ------------------------------------------------------------------------------------------------
@@ -256,11 +331,27 @@ int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float*
     return check_launch("gn backward");
 }
 
+// scratch: one d-gain row per workgroup of 256 pixel rows, and 32 rows for the first level of their sum
+size_t ln_bwd_scratch_floats(size_t P, int C) { return ((P + 255) / 256 + 32) * (size_t)C; }
+
 int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st) {
-    const int rows = 64;
+    if (C % 64 || C > 512 || (C > 256 && C != 512)) { hd_set_error("ln backward: channels must be 64, 128, 192, 256 or 512"); return -1; }
+    const int rows = 256;
     const unsigned nb = (unsigned)((P + rows - 1) / rows);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), (size_t)4 * C * sizeof(float), st, x, dy, dout, gain, P, C, rows, scratch);
-    hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, (int)nb, C, accumulate, dgain);
+    const int nv = C == 512 ? 2 : 1, lpr = C / (4 * nv);
+    if (64 % lpr) { hd_set_error("ln backward: unsupported channel count"); return -1; }
+    const size_t lds = (size_t)4 * (64 / lpr) * C * sizeof(float);
+    if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch);
+    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch);
+    // sum over the workgroups' rows: two levels when there are many (one thread per column walking thousands of rows was 47 us)
+    if (nb >= 256) {
+        float* lvl = scratch + (size_t)nb * C;
+        const int per = (int)((nb + 31) / 32);
+        hipLaunchKernelGGL(col_sum_groups_kernel, dim3((C + 255) / 256, 32), dim3(256), 0, st, scratch, (int)nb, per, C, lvl);
+        hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, lvl, 32, C, accumulate, dgain);
+    } else {
+        hipLaunchKernelGGL(col_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, scratch, (int)nb, C, accumulate, dgain);
+    }
     return check_launch("ln backward");
 }
 
@@ -296,7 +387,7 @@ int hd_debug_ln_bwd(const float* x, float* dy, const float* gain, long long P, i
     if (!x || !dy || !gain || !dgain || P < 1 || C < 1) return HD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     float* scratch = nullptr;
-    if (hipMalloc(&scratch, ((size_t)(P + 63) / 64) * C * sizeof(float)) != hipSuccess) return HD_ENOMEM;
+    if (hipMalloc(&scratch, ln_bwd_scratch_floats((size_t)P, C) * sizeof(float)) != hipSuccess) return HD_ENOMEM;
     const int rc = launch_ln_bwd(x, dy, dy, gain, (size_t)P, C, scratch, dgain, 0, st);
     (void)hipStreamSynchronize(st);
     (void)hipFree(scratch);

@@ -422,7 +422,7 @@ def test_groupnorm_film_silu_backward_component(B, S, Cc, film):
         assert rel_err(fs.grad, df) <= 1e-4
 
 
-@pytest.mark.parametrize("P_,Cc", [(200, 64), (1000, 128), (75, 512)])
+@pytest.mark.parametrize("P_,Cc", [(200, 64), (1000, 128), (75, 512), (300, 256), (70000, 64)])
 def test_channel_layernorm_backward_component(P_, Cc):
     import ctypes as C
     P = C.c_void_p
