@@ -272,9 +272,223 @@ __global__ __launch_bounds__(256, 2) void wgrad_gemm_kernel(const unsigned short
     }
 }
 
+// ---- weight gradient straight from the NHWC fp32 tensors (no operand rewrite) ---------------------------------------------------
+// Same product and the same partial layout as wgrad_gemm_kernel, but the operands are read where the forward left them:
+// activations X [B][H][W][C0 (+ C1)] (channel concat = two pointers) and output gradient G [B][H][W][F], fp32.  k runs over a padded
+// pixel space of pitch W + 1 with H + 1 rows per sample (one zero column / row is all the isolation the 3 x 3 taps need), 64 positions
+// per slice.  The loader (thread = 4 pixels x one channel quad of G and one or two of X) splits each float4 into bf16 hi / lo on the
+// fly and writes [pixel][channel] images into LDS; the MFMA fragments -- 8 consecutive k per lane, i.e. a COLUMN of that image --
+// come out of it with ds_read_b64_tr_b16 (tools/tr_read_probe.hip pins the lane mapping).  The column taps are whole-row offsets of
+// the G image (pixel k + 1 - kx), the row tap dy is a shift of the X source row, zero outside the map.  The four pixel rows of a
+// transposed read must fall on disjoint bank quarters: G rows are 128 + 64 bytes, X rows are swizzled in 64-byte chunks.
+// Bias gradient: the workgroups of the first row tile (centre row tap) also sum their G slices per channel -> biaspart[split][F].
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+struct WgdArgs {
+    const float* x0; const float* x1; int C0, C1;
+    const float* g; int F;
+    int B, H, W; unsigned magicW, magicH;                  // floor(n / (W+1)) = umulhi(n, magicW), same for H + 1
+    int slices_per_split, total_slices, nsplit, Mtiles, Ntiles, M;
+    float* partial; float* biaspart; int xcd_group;
+};
+
+__device__ __forceinline__ uint2 split_quad(const float4& v, uint2& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 h0 = {(__bf16)v.x, (__bf16)v.y}, h1 = {(__bf16)v.z, (__bf16)v.w};
+    const bf2 l0 = {(__bf16)(v.x - (float)h0[0]), (__bf16)(v.y - (float)h0[1])}, l1 = {(__bf16)(v.z - (float)h1[0]), (__bf16)(v.w - (float)h1[1])};
+    lo = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+    return make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+}
+__device__ __forceinline__ bf16x8 tr_read8(const char* p, int second) {      // 8 consecutive pixels of this lane's channel: two 4-pixel blocks
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + second));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <bool ONE, int TMW>
+__global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
+    // bytes per pixel row: the G image is padded (its taps are row offsets), the X image is XOR-swizzled instead (never shifted): 64-byte
+    // chunk index ^= pixel & 3 (256-byte rows) or ^= (pixel >> 1) & 1 (128-byte rows)
+    constexpr int BM = 64 * TMW, PX = BM * 2, PG = 64 * 2 + 64;
+    constexpr int XHI = 0, XLO = 64 * PX, GHI = 2 * 64 * PX, GLO = GHI + 66 * PG, LDSB = GLO + 66 * PG;
+    __shared__ __attribute__((aligned(16))) char smem[LDSB];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = w >> 1, wn = w & 1;
+    const int per = a.Mtiles * a.Ntiles;
+    int split, inner;
+    if ((a.nsplit & 7) == 0 && a.xcd_group) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
+    else { split = blockIdx.x / per; inner = blockIdx.x % per; }
+    const int nt = inner % a.Ntiles, mt = inner / a.Ntiles;
+    const int dyi = ONE ? 1 : (int)blockIdx.y, dy = dyi - 1;
+    constexpr int NDX = ONE ? 1 : 3;
+    const int Wp = a.W + 1, Hp = a.H + 1, Ktot = a.B * Hp * Wp, Cin = a.C0 + a.C1;
+    const int s0 = split * a.slices_per_split;
+    const int nslices = min(a.slices_per_split, a.total_slices - s0);
+    const bool do_bias = a.biaspart != nullptr && mt == 0 && dyi == 1;
+
+    // ---- loader roles: pixel group pg (pixels pg + 16 j of a slice), channel quad
+    const int pg = tid >> 4, quad = tid & 15;
+    const int gch = nt * 64 + quad * 4;                                          // F is a multiple of 64
+    int xch[TMW]; const float* xsrc[TMW]; int xC[TMW]; bool xok[TMW];
+#pragma unroll
+    for (int t = 0; t < TMW; ++t) {
+        const int c = mt * BM + t * 64 + quad * 4;
+        xok[t] = c < Cin;
+        if (c < a.C0) { xsrc[t] = a.x0 + c; xC[t] = a.C0; } else { xsrc[t] = a.x1 + (c - a.C0); xC[t] = a.C1; }
+        if (!xok[t]) { xsrc[t] = a.x0; xC[t] = a.C0; }
+        xch[t] = c;
+    }
+    float4 rX[4 * TMW], rG[4], rGh = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned vmask = 0;                                                          // bits 0-3: G item j valid; 4-7: X pixel j valid; 8: halo valid
+    auto locate = [&](int kp, int& gpix, bool& gv, int& xpix, bool& xv) {      // padded position -> source pixels
+        const bool in = kp >= 0 && kp < Ktot;
+        const unsigned k = in ? (unsigned)kp : 0u;
+        const unsigned yq = __umulhi(k, a.magicW), xp = k - yq * Wp, b = __umulhi(yq, a.magicH), yp = yq - b * Hp;
+        gv = in && (int)xp < a.W && (int)yp < a.H;
+        const int ys = (int)yp + dy;
+        xv = in && (int)xp < a.W && ys >= 0 && ys < a.H;
+        gpix = ((int)b * a.H + (int)yp) * a.W + (int)xp;
+        xpix = ((int)b * a.H + ys) * a.W + (int)xp;
+    };
+    auto request = [&](int s) {
+        const int k0 = (s0 + s) * 64;
+        vmask = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int gp, xp; bool gv, xv;
+            locate(k0 + pg + 16 * j, gp, gv, xp, xv);
+            rG[j] = *reinterpret_cast<const float4*>(a.g + (size_t)(gv ? gp : 0) * a.F + gch);
+            vmask |= (gv ? 1u : 0u) << j;
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) rX[j * TMW + t] = *reinterpret_cast<const float4*>(xsrc[t] + (size_t)(xv ? xp : 0) * xC[t]);
+            vmask |= (xv ? 1u : 0u) << (4 + j);
+        }
+        if (!ONE && tid < 32) {                                                  // the G halo: positions k0 - 1 and k0 + 64
+            int gp, xp; bool gv, xv;
+            locate(tid < 16 ? k0 - 1 : k0 + 64, gp, gv, xp, xv);
+            rGh = *reinterpret_cast<const float4*>(a.g + (size_t)(gv ? gp : 0) * a.F + gch);
+            vmask |= (gv ? 1u : 0u) << 8;
+        }
+    };
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int xswz_w = (TMW == 2 ? (pg & 3) : ((pg >> 1) & 1)) << 6;             // pixel = pg + 16 j: its low bits are pg's
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pl = pg + 16 * j;
+            const float4 gq = (vmask >> j) & 1 ? rG[j] : zero4;
+            if (do_bias) { bsum.x += gq.x; bsum.y += gq.y; bsum.z += gq.z; bsum.w += gq.w; }
+            uint2 lo; const uint2 hi = split_quad(gq, lo);
+            *reinterpret_cast<uint2*>(smem + GHI + (pl + 1) * PG + quad * 8) = hi;
+            *reinterpret_cast<uint2*>(smem + GLO + (pl + 1) * PG + quad * 8) = lo;
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                const float4 xq = ((vmask >> (4 + j)) & 1) && xok[t] ? rX[j * TMW + t] : zero4;
+                uint2 xl; const uint2 xh = split_quad(xq, xl);
+                const int xo = pl * PX + ((t * 128 + quad * 8) ^ xswz_w);
+                *reinterpret_cast<uint2*>(smem + XHI + xo) = xh;
+                *reinterpret_cast<uint2*>(smem + XLO + xo) = xl;
+            }
+        }
+        if (!ONE && tid < 32) {
+            const float4 gq = (vmask >> 8) & 1 ? rGh : zero4;
+            uint2 lo; const uint2 hi = split_quad(gq, lo);
+            const int row = tid < 16 ? 0 : 65;
+            *reinterpret_cast<uint2*>(smem + GHI + row * PG + quad * 8) = hi;
+            *reinterpret_cast<uint2*>(smem + GLO + row * PG + quad * 8) = lo;
+        }
+    };
+
+    // ---- fragment addresses: lane 4q + p of 16-lane group gq supplies (pixel row q, channels 4p .. 4p + 3) of its group's block;
+    // group = (channel half = bit 0, k half = bit 1)
+    const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int prow = 8 * (grp >> 1) + q4;                                        // + 16 ks (+ 4 for the second block)
+    int xoff[TMW];                                                               // the pixel's low bits are q4's (every other term is a multiple of 4)
+#pragma unroll
+    for (int t = 0; t < TMW; ++t)
+        xoff[t] = prow * PX + ((((wm * TMW + t) * 32 + 16 * (grp & 1) + 4 * p4) * 2) ^ ((TMW == 2 ? (q4 & 3) : ((q4 >> 1) & 1)) << 6));
+    const int goff = (prow + 1) * PG + (wn * 32 + 16 * (grp & 1) + 4 * p4) * 2;   // G pixel k sits in row k + 1
+
+    f32x16 acc[TMW][NDX];
+#pragma unroll
+    for (int t = 0; t < TMW; ++t)
+#pragma unroll
+        for (int x = 0; x < NDX; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][x][r] = 0.f;
+
+    request(0);
+    for (int s = 0; s < nslices; ++s) {
+        store();
+        __syncthreads();
+        request(min(s + 1, nslices - 1));
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 ah[TMW], al[TMW];
+#pragma unroll
+            for (int t = 0; t < TMW; ++t) {
+                ah[t] = tr_read8(smem + XHI + xoff[t] + ks * 16 * PX, 4 * PX);
+                al[t] = tr_read8(smem + XLO + xoff[t] + ks * 16 * PX, 4 * PX);
+            }
+#pragma unroll
+            for (int dx = 0; dx < NDX; ++dx) {
+                // kx = dx: G[k + 1 - kx] (the centre tap only for a 1 x 1 filter)
+                const int sh = ONE ? 0 : (1 - dx) * PG;
+                const bf16x8 bh = tr_read8(smem + GHI + goff + ks * 16 * PG + sh, 4 * PG);
+                const bf16x8 bl = tr_read8(smem + GLO + goff + ks * 16 * PG + sh, 4 * PG);
+#pragma unroll
+                for (int t = 0; t < TMW; ++t) {
+                    acc[t][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh, acc[t][dx], 0, 0, 0);
+                    acc[t][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl, acc[t][dx], 0, 0, 0);
+                    acc[t][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh, acc[t][dx], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int N = NDX * a.F;
+    float* out = a.partial + ((size_t)(split * NDX + (ONE ? 0 : dyi)) * a.M) * N;
+#pragma unroll
+    for (int t = 0; t < TMW; ++t)
+#pragma unroll
+        for (int dx = 0; dx < NDX; ++dx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + (wm * TMW + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int n = dx * a.F + nt * 64 + wn * 32 + l31;
+                out[(size_t)m * N + n] = acc[t][dx][r];
+            }
+    if (do_bias) {                                                               // uniform per workgroup
+        float* red = reinterpret_cast<float*>(smem);                             // [16 pixel groups][64 channels]; the images are dead
+        *reinterpret_cast<float4*>(red + pg * 64 + quad * 4) = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+            for (int k = 0; k < 16; ++k) t += red[k * 64 + tid];
+            a.biaspart[(size_t)split * a.F + nt * 64 + tid] = t;
+        }
+    }
+}
+
 // dW[co][ci][ky][kx] (torch layout, KT x KT taps, KT = 3 or 1) (+)= scale * sum_split partial[split][ky][ci (< Mpad)][kx*Cout + co]
 __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ partial, int nsplit, int Cin, int Mpad, int Cout, int KT, float scale,
-                                                        int accumulate, float* __restrict__ dW) {
+                                                        int accumulate, float* __restrict__ dW, const float* __restrict__ biaspart = nullptr,
+                                                        float* __restrict__ db = nullptr, int nmain = 0) {
+    if (db && (int)blockIdx.x >= nmain) {                              // trailing blocks: db[co] = sum_split biaspart[split][co]
+        const int co = ((int)blockIdx.x - nmain) * 256 + threadIdx.x;
+        if (co >= Cout) return;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += biaspart[(size_t)(sp + j) * Cout + co];
+        }
+        for (; sp < nsplit; ++sp) a[sp & 7] += biaspart[(size_t)sp * Cout + co];
+        db[co] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        return;
+    }
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [KT][Mpad][KT*Cout]
     const size_t per = (size_t)KT * Mpad * KT * Cout;
     if (i >= per) return;
@@ -609,6 +823,55 @@ struct Wgrad {
         conv_prof_end(st);
         return check_launch("wg_prep");
     }
+    // splits of a call: the three row taps are separate workgroups, and k is cut until ~one round of workgroups exists (two fit a CU),
+    // each keeping at least 8 slices of 64 and the partials fitting their buffer.  (Round 1 cut k only 40 / 8 / 4 ways on the 32x32 /
+    // 16x16 / 8x8 maps: 64-128 workgroups on 256 CUs, each looping over the three row taps.)  Measured (MI355X, 64 tiles): the UNet's
+    // layers (1-12 tiles per split) are fastest with ONE round of 512 workgroups (39.0 ms per step; 40.7-40.8 at 256 / 768 / 1024),
+    // hicedrn's 24-tile layers with 960 (0.96 ms per GEMM; 1.02 at 384).
+    int pick_splits(int tiles, int total_slices, size_t per_split_floats, int* slices_per_split) const {
+        static const int target_env = getenv("HICDIFF_WG_TARGET") ? atoi(getenv("HICDIFF_WG_TARGET")) : 0;
+        const int target = target_env ? target_env : (tiles >= 16 ? 1024 : 512);
+        int eff = std::max(1, target / tiles);
+        eff = std::min<int>(eff, std::max(1, total_slices / 8));
+        eff = (int)std::min<size_t>((size_t)eff, partial_floats / (per_split_floats + 1024));   // + room for a bias row per split
+        if (eff >= 8) eff &= ~7;
+        eff = std::max(eff, 1);
+        const int sps = (total_slices + eff - 1) / eff;
+        *slices_per_split = sps;
+        return (total_slices + sps - 1) / sps;                 // no empty split
+    }
+    // weight (+ bias) gradient of a KT x KT stride-1 same-padded convolution straight from the NHWC tensors (wgrad_direct_kernel):
+    // activations (x0 | x1) [B][H][W][C0 + C1], output gradient g [B][H][W][Cout]; dW in the torch layout, db (optional) [Cout]
+    int run_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, int KT, float* dW, float* db, hipStream_t st) const {
+        static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
+        const int Cin = C0 + C1;
+        const bool m64 = Cin <= 64;
+        const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
+        if (Cout % 64 || Cout > 1024 || C0 % 4 || C1 % 4 || (KT != 1 && KT != 3) || !x0 || (C1 && !x1)) { hd_set_error("wgrad (direct): unsupported shape"); return -1; }
+        const long long Ktot = (long long)B * (H + 1) * (W + 1);
+        if (Ktot >= (1ll << 31) / (W + 2)) { hd_set_error("wgrad (direct): too many pixels for the 32-bit position arithmetic"); return -1; }
+        const int ndy = KT == 3 ? 3 : 1, total = (int)((Ktot + 63) / 64);
+        const size_t per_split_floats = (size_t)KT * KT * Mpad * Cout;
+        if (per_split_floats + 1024 > partial_floats) { hd_set_error("wgrad (direct): the partial buffer is too small for this layer"); return -1; }
+        int sps = 0;
+        const int eff = pick_splits(Mt * Nt * ndy, total, per_split_floats, &sps);
+        WgdArgs a{};
+        a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.g = g; a.F = Cout; a.B = B; a.H = H; a.W = W;
+        a.magicW = (unsigned)((1ull << 32) / (unsigned)(W + 1)) + 1u; a.magicH = (unsigned)((1ull << 32) / (unsigned)(H + 1)) + 1u;
+        a.slices_per_split = sps; a.total_slices = total; a.nsplit = eff; a.Mtiles = Mt; a.Ntiles = Nt; a.M = Mpad;
+        a.partial = partial; a.biaspart = db ? partial + (size_t)eff * per_split_floats : nullptr; a.xcd_group = xcd_group;
+        const char* name = KT == 1 ? "wgrad_direct_kernel<true>" : "wgrad_direct_kernel<false>";
+        hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
+        const dim3 grid(Mt * Nt * eff, ndy);
+        if (KT == 1) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<true, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<true, 2>), grid, dim3(256), 0, st, a); }
+        else { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2>), grid, dim3(256), 0, st, a); }
+        conv_prof_end(st);
+        if (check_launch("wgrad direct")) return -3;
+        const int nmain = (int)((per_split_floats + 255) / 256);
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)(nmain + (db ? (Cout + 255) / 256 : 0))), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, 1.f, 0, dW,
+                           a.biaspart, db, nmain);
+        return check_launch("wg_reduce");
+    }
     // dW[Cout][Cin][KT][KT] (+)= scale * sum over pixels (activation image rows 0..Cin-1, gradient image rows 0..Cout-1)
     int run(int Cin, int Cout, int KT, float scale, bool accumulate, float* dW, bool plain, hipStream_t st) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
@@ -617,22 +880,10 @@ struct Wgrad {
         const bool m64 = Cin <= 64 && !no64;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
         if (Cout % 64 || Mpad > maxCin || Cout > maxCout || (KT != 1 && KT != 3)) { hd_set_error("wgrad: unsupported shape"); return -1; }
-        // splits of this call: the three row taps are separate workgroups, and k is cut until ~two rounds of workgroups exist (two
-        // fit a CU), each keeping at least 8 slices of 64 and the partials fitting their buffer.  (Round 1 cut k only 40 / 8 / 4 ways on
-        // the 32x32 / 16x16 / 8x8 maps: 64-128 workgroups on 256 CUs, each looping over the three row taps.)
-        // Measured (MI355X, 64 tiles): the UNet's layers (1-12 tiles per split) are fastest with ONE round of 512 workgroups (39.0 ms per
-        // step; 40.7-40.8 at 256 / 768 / 1024), hicedrn's 24-tile layers with 960 (0.96 ms per GEMM; 1.02 at 384).
-        static const int target_env = getenv("HICDIFF_WG_TARGET") ? atoi(getenv("HICDIFF_WG_TARGET")) : 0;
         const int ndy = KT == 3 ? 3 : 1, total = (int)(Kpad / 64);
-        const int target = target_env ? target_env : (Mt * Nt * ndy >= 16 ? 1024 : 512);
         const size_t per_split_floats = (size_t)KT * KT * Mpad * Cout;
-        int eff = std::max(1, target / (Mt * Nt * ndy));
-        eff = std::min<int>(eff, std::max(1, total / 8));
-        eff = (int)std::min<size_t>((size_t)eff, partial_floats / per_split_floats);
-        if (eff >= 8) eff &= ~7;
-        eff = std::max(eff, 1);
-        const int sps = (total + eff - 1) / eff;
-        eff = (total + sps - 1) / sps;                      // no empty split
+        int sps = 0;
+        const int eff = pick_splits(Mt * Nt * ndy, total, per_split_floats, &sps);
         // algorithmic figures: KT*KT taps x Cin x Cout outputs over the B*H*W real pixels (3 MFMA flops per product are the kernel's business);
         // bytes: both operand images once (hi + lo) + the partials
         const char* name = KT == 1 ? (plain ? "wgrad_gemm_kernel<true, true>" : "wgrad_gemm_kernel<false, true>")
@@ -1083,6 +1334,18 @@ extern "C" int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C,
     if (!g || !dx || B < 1 || C % 4) return HD_EINVAL;
     const int rc = which == 1 ? launch_sum_pool2(g, B, H, W, C, dx, (hipStream_t)stream) : launch_pixel_shuffle(g, B, H, W, C, dx, (hipStream_t)stream);
     (void)hipStreamSynchronize((hipStream_t)stream);
+    return rc ? HD_EHIP : HD_OK;
+}
+
+extern "C" int hd_debug_conv_wgrad_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT, float* dW,
+                                          float* db, void* stream) {
+    if (!x0 || !g || !dW || B < 1 || H < 1 || W < 1 || C0 % 4 || C1 % 4 || (C1 && !x1) || Cout % 64 || (KT != 1 && KT != 3)) return HD_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    Wgrad wg;
+    if (!wg.init(B, H, W, 128, 64)) { wg.destroy(); return HD_ENOMEM; }      // only its partial buffer is used
+    const int rc = wg.run_direct(x0, C0, x1, C1, g, Cout, KT, dW, db, st);
+    (void)hipStreamSynchronize(st);
+    wg.destroy();
     return rc ? HD_EHIP : HD_OK;
 }
 

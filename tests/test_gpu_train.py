@@ -382,6 +382,36 @@ def test_weight_gradient_component_any_shape(B, S, C0, C1, Cout, KT, aff, plain)
     assert rel_err(ref, out) <= (2e-2 if plain else 1e-4)
 
 
+@pytest.mark.parametrize("B,S,C0,C1,Cout,KT", [
+    (2, 10, 64, 0, 64, 3),          # 64-row tile; map width 10 (padded pitch 11)
+    (3, 5, 128, 64, 128, 3),        # channel concat, 192 input channels in a 256-row tile pair, 5x5 map
+    (2, 20, 128, 64, 64, 1),        # 1x1 filter
+    (1, 64, 64, 0, 64, 3),
+    (2, 8, 512, 512, 512, 3),       # the widest UNet layer
+    (5, 16, 256, 0, 384, 1),        # to_qkv
+    (4, 32, 128, 0, 128, 3),
+])
+def test_weight_gradient_direct_from_nhwc(B, S, C0, C1, Cout, KT):
+    """wgrad_direct_kernel (operands read as the forward left them, transposed LDS reads) against torch's conv2d weight gradient and
+    the bias gradient against the pixel sum."""
+    import ctypes as C
+    P = C.c_void_p
+    fn = _dbg("hd_debug_conv_wgrad_direct", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, P])
+    gen = torch.Generator().manual_seed(B * 1000 + S + KT)
+    Cin = C0 + C1
+    x = torch.randn((B, Cin, S, S), generator=gen)
+    g = torch.randn((B, Cout, S, S), generator=gen) * 0.1
+    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, KT, KT), g, padding=KT // 2)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    x0, x1 = nhwc(x[:, :C0]), (nhwc(x[:, C0:]) if C1 else None)
+    gd, out, db = nhwc(g), torch.empty((Cout, Cin, KT, KT), device="cuda"), torch.empty(Cout, device="cuda")
+    ptr = lambda t: P(t.data_ptr()) if t is not None else P()
+    rc = fn(ptr(x0), C0, ptr(x1), C1, ptr(gd), B, S, S, Cout, KT, ptr(out), ptr(db), P(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    assert rel_err(ref, out) <= 1e-4
+    assert rel_err(g.sum(dim=(0, 2, 3)), db) <= 1e-5
+
+
 def _dbg(name, argtypes):
     import ctypes as C
     from hicdiff_amd import _lib as L
