@@ -289,6 +289,8 @@ struct WgdArgs {
     int B, H, W; unsigned magicW, magicH;                  // floor(n / (W+1)) = umulhi(n, magicW), same for H + 1
     int slices_per_split, total_slices, nsplit, Mtiles, Ntiles, M;
     float* partial; float* biaspart; int xcd_group;
+    int src_mode;                                          // 0: X as [B][H][W][C]; 1: nearest x2 upsample of [B][H/2][W/2][C]; 2: pixel-unshuffle of [B][2H][2W][C/4]
+    const float* affA; const float* affB; const float* affE; int aff_bs;   // AFF kernels: X = silu(x * affA[b][c] + affB[b][c]) (+ affE[b][c])
 };
 
 __device__ __forceinline__ uint2 split_quad(const float4& v, uint2& lo) {
@@ -306,8 +308,13 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int second) {      // 
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <bool ONE, int TMW>
+// AFF: 0 = X as stored; 1 = a normalised activation recomputed on the way in, silu(x A + B) per (sample, channel); 2 = the same + E after
+// the SiLU (SR3's additive embedding).  The coefficients of each item travel with its prefetch (8-12 more registers per pixel), which
+// fits the 64-row tile only: AFF kernels are instantiated with TMW = 1.
+// SRC: source addressing of X (WgdArgs::src_mode) -- compiled in, the position arithmetic sits in the loop.
+template <bool ONE, int TMW, int AFF = 0, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
+    static_assert(AFF == 0 || TMW == 1, "the affine-input form uses the 64-row tile");
     // bytes per pixel row: the G image is padded (its taps are row offsets), the X image is XOR-swizzled instead (never shifted): 64-byte
     // chunk index ^= pixel & 3 (256-byte rows) or ^= (pixel >> 1) & 1 (128-byte rows)
     constexpr int BM = 64 * TMW, PX = BM * 2, PG = 64 * 2 + 64;
@@ -340,7 +347,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
         xch[t] = c;
     }
     float4 rX[4 * TMW], rG[4], rGh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cA[AFF ? 4 : 1], cB[AFF ? 4 : 1], cE[AFF == 2 ? 4 : 1];
     unsigned vmask = 0;                                                          // bits 0-3: G item j valid; 4-7: X pixel j valid; 8: halo valid
+    int sample = 0;
     auto locate = [&](int kp, int& gpix, bool& gv, int& xpix, bool& xv) {      // padded position -> source pixels
         const bool in = kp >= 0 && kp < Ktot;
         const unsigned k = in ? (unsigned)kp : 0u;
@@ -349,7 +358,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
         const int ys = (int)yp + dy;
         xv = in && (int)xp < a.W && ys >= 0 && ys < a.H;
         gpix = ((int)b * a.H + (int)yp) * a.W + (int)xp;
-        xpix = ((int)b * a.H + ys) * a.W + (int)xp;
+        if constexpr (SRC == 1) xpix = ((int)b * (a.H >> 1) + (ys >> 1)) * (a.W >> 1) + ((int)xp >> 1);          // Upsample, src/hicdiff.py:72-76
+        else if constexpr (SRC == 2) xpix = ((int)b * 2 * a.H + 2 * ys) * 2 * a.W + 2 * (int)xp;                  // top-left of the 2 x 2 source block
+        else xpix = ((int)b * a.H + ys) * a.W + (int)xp;
+        sample = in ? (int)b : 0;
     };
     auto request = [&](int s) {
         const int k0 = (s0 + s) * 64;
@@ -361,8 +373,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
             rG[j] = *reinterpret_cast<const float4*>(a.g + (size_t)(gv ? gp : 0) * a.F + gch);
             vmask |= (gv ? 1u : 0u) << j;
 #pragma unroll
-            for (int t = 0; t < TMW; ++t) rX[j * TMW + t] = *reinterpret_cast<const float4*>(xsrc[t] + (size_t)(xv ? xp : 0) * xC[t]);
+            for (int t = 0; t < TMW; ++t) {
+                if constexpr (SRC == 2) {
+                    // Downsample (src/hicdiff.py:78-82): logical channel c * 4 + p1 * 2 + p2 reads source pixel (2y + p1, 2x + p2), channel c:
+                    // this quad is one source channel of the four pixels of the 2 x 2 block
+                    const int Cs = a.C0 >> 2;
+                    const float* sp = a.x0 + (size_t)(xv ? xp : 0) * Cs + (xok[t] ? xch[t] >> 2 : 0);
+                    const size_t rowp = (size_t)2 * a.W * Cs;
+                    rX[j * TMW + t] = make_float4(sp[0], sp[Cs], sp[rowp], sp[rowp + Cs]);
+                } else {
+                    rX[j * TMW + t] = *reinterpret_cast<const float4*>(xsrc[t] + (size_t)(xv ? xp : 0) * xC[t]);
+                }
+            }
             vmask |= (xv ? 1u : 0u) << (4 + j);
+            if constexpr (AFF != 0) {
+                const size_t co = (size_t)sample * a.aff_bs + (xok[0] ? xch[0] : 0);
+                cA[j] = *reinterpret_cast<const float4*>(a.affA + co);
+                cB[j] = *reinterpret_cast<const float4*>(a.affB + co);
+                if constexpr (AFF == 2) cE[j] = *reinterpret_cast<const float4*>(a.affE + co);
+            }
         }
         if (!ONE && tid < 32) {                                                  // the G halo: positions k0 - 1 and k0 + 64
             int gp, xp; bool gv, xv;
@@ -385,7 +414,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
             *reinterpret_cast<uint2*>(smem + GLO + (pl + 1) * PG + quad * 8) = lo;
 #pragma unroll
             for (int t = 0; t < TMW; ++t) {
-                const float4 xq = ((vmask >> (4 + j)) & 1) && xok[t] ? rX[j * TMW + t] : zero4;
+                float4 xq = rX[j * TMW + t];
+                if constexpr (AFF != 0) {
+                    xq = make_float4(silu_f(xq.x * cA[j].x + cB[j].x), silu_f(xq.y * cA[j].y + cB[j].y), silu_f(xq.z * cA[j].z + cB[j].z),
+                                     silu_f(xq.w * cA[j].w + cB[j].w));
+                    if constexpr (AFF == 2) { xq.x += cE[j].x; xq.y += cE[j].y; xq.z += cE[j].z; xq.w += cE[j].w; }
+                }
+                if (!(((vmask >> (4 + j)) & 1) && xok[t])) xq = zero4;           // zero padding applies to the transformed tensor
                 uint2 xl; const uint2 xh = split_quad(xq, xl);
                 const int xo = pl * PX + ((t * 128 + quad * 8) ^ xswz_w);
                 *reinterpret_cast<uint2*>(smem + XHI + xo) = xh;
@@ -842,10 +877,12 @@ struct Wgrad {
     }
     // weight (+ bias) gradient of a KT x KT stride-1 same-padded convolution straight from the NHWC tensors (wgrad_direct_kernel):
     // activations (x0 | x1) [B][H][W][C0 + C1], output gradient g [B][H][W][Cout]; dW in the torch layout, db (optional) [Cout]
-    int run_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, int KT, float* dW, float* db, hipStream_t st) const {
+    // affA / affB (/ affE), all [B][C0 + C1] or null: the input is silu(x affA + affB) (+ affE) per (sample, channel)
+    int run_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, int KT, float* dW, float* db, hipStream_t st,
+                   const float* affA = nullptr, const float* affB = nullptr, const float* affE = nullptr, int src_mode = 0) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         const int Cin = C0 + C1;
-        const bool m64 = Cin <= 64;
+        const bool m64 = Cin <= 64 || affA;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
         if (Cout % 64 || Cout > 1024 || C0 % 4 || C1 % 4 || (KT != 1 && KT != 3) || !x0 || (C1 && !x1)) { hd_set_error("wgrad (direct): unsupported shape"); return -1; }
         const long long Ktot = (long long)B * (H + 1) * (W + 1);
@@ -860,10 +897,19 @@ struct Wgrad {
         a.magicW = (unsigned)((1ull << 32) / (unsigned)(W + 1)) + 1u; a.magicH = (unsigned)((1ull << 32) / (unsigned)(H + 1)) + 1u;
         a.slices_per_split = sps; a.total_slices = total; a.nsplit = eff; a.Mtiles = Mt; a.Ntiles = Nt; a.M = Mpad;
         a.partial = partial; a.biaspart = db ? partial + (size_t)eff * per_split_floats : nullptr; a.xcd_group = xcd_group;
+        a.affA = affA; a.affB = affB; a.affE = affE; a.aff_bs = Cin; a.src_mode = src_mode;
+        if (src_mode && (C1 || affA || m64 || src_mode > 2 || (src_mode == 1 && (KT != 3 || ((H | W) & 1))) || (src_mode == 2 && KT != 1))) {
+            hd_set_error("wgrad (direct): unsupported source addressing");
+            return -1;
+        }
+        if (affA && (!affB || KT != 3)) { hd_set_error("wgrad (direct): the affine-input form is the 3 x 3 one and needs both coefficient arrays"); return -1; }
         const char* name = KT == 1 ? "wgrad_direct_kernel<true>" : "wgrad_direct_kernel<false>";
         hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
         const dim3 grid(Mt * Nt * eff, ndy);
-        if (KT == 1) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<true, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<true, 2>), grid, dim3(256), 0, st, a); }
+        if (src_mode == 1) hipLaunchKernelGGL((wgrad_direct_kernel<false, 2, 0, 1>), grid, dim3(256), 0, st, a);
+        else if (src_mode == 2) hipLaunchKernelGGL((wgrad_direct_kernel<true, 2, 0, 2>), grid, dim3(256), 0, st, a);
+        else if (KT == 1) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<true, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<true, 2>), grid, dim3(256), 0, st, a); }
+        else if (affA) { if (affE) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 1>), grid, dim3(256), 0, st, a); }
         else { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2>), grid, dim3(256), 0, st, a); }
         conv_prof_end(st);
         if (check_launch("wgrad direct")) return -3;
@@ -1338,12 +1384,12 @@ extern "C" int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C,
 }
 
 extern "C" int hd_debug_conv_wgrad_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT, float* dW,
-                                          float* db, void* stream) {
+                                          float* db, const float* affA, const float* affB, const float* affE, int src_mode, void* stream) {
     if (!x0 || !g || !dW || B < 1 || H < 1 || W < 1 || C0 % 4 || C1 % 4 || (C1 && !x1) || Cout % 64 || (KT != 1 && KT != 3)) return HD_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     Wgrad wg;
     if (!wg.init(B, H, W, 128, 64)) { wg.destroy(); return HD_ENOMEM; }      // only its partial buffer is used
-    const int rc = wg.run_direct(x0, C0, x1, C1, g, Cout, KT, dW, db, st);
+    const int rc = wg.run_direct(x0, C0, x1, C1, g, Cout, KT, dW, db, st, affA, affB, affE, src_mode);
     (void)hipStreamSynchronize(st);
     wg.destroy();
     return rc ? HD_EHIP : HD_OK;

@@ -45,9 +45,10 @@ int hd_debug_linattn_q(const float* x, const float* norm_g, const float* wqkv, c
 int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT,
                         const float* affA, const float* affB, int plain, float* dW, void* stream);
 /* The same gradient straight from the NHWC tensors (csrc/train.hip, wgrad_direct_kernel: no operand rewrite; split-bf16 x3 only), plus the
- * bias gradient db[Cout] = sum over pixels of g (db may be NULL). */
+ * bias gradient db[Cout] = sum over pixels of g (db may be NULL).  affA / affB / affE ([B][C0+C1], may be NULL; KT = 3 only): the input is
+ * silu(x * affA + affB) + affE per (sample, channel).  src_mode: source addressing of x0 as hd_debug_conv_wgrad's plain >> 1 (0, 1 = upsample, 2 = unshuffle). */
 int hd_debug_conv_wgrad_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT,
-                               float* dW, float* db, void* stream);
+                               float* dW, float* db, const float* affA, const float* affB, const float* affE, int src_mode, void* stream);
 
 /* Backward components of the UNet's normalisations (csrc/train_norms.hip; groundwork for its training step), against torch autograd:
  *   hd_debug_gn_silu_bwd  y = silu(GroupNorm_G(x) * (scale + 1) + shift) (src/hicdiff.py:155-171): x NHWC [B,H,W,C]; g holds dL/dy on entry and

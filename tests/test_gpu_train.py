@@ -382,31 +382,44 @@ def test_weight_gradient_component_any_shape(B, S, C0, C1, Cout, KT, aff, plain)
     assert rel_err(ref, out) <= (2e-2 if plain else 1e-4)
 
 
-@pytest.mark.parametrize("B,S,C0,C1,Cout,KT", [
-    (2, 10, 64, 0, 64, 3),          # 64-row tile; map width 10 (padded pitch 11)
-    (3, 5, 128, 64, 128, 3),        # channel concat, 192 input channels in a 256-row tile pair, 5x5 map
-    (2, 20, 128, 64, 64, 1),        # 1x1 filter
-    (1, 64, 64, 0, 64, 3),
-    (2, 8, 512, 512, 512, 3),       # the widest UNet layer
-    (5, 16, 256, 0, 384, 1),        # to_qkv
-    (4, 32, 128, 0, 128, 3),
+@pytest.mark.parametrize("B,S,C0,C1,Cout,KT,aff", [
+    (2, 10, 64, 0, 64, 3, 0),          # 64-row tile; map width 10 (padded pitch 11)
+    (3, 5, 128, 64, 128, 3, 0),        # channel concat, 192 input channels in a 256-row tile pair, 5x5 map
+    (2, 20, 128, 64, 64, 1, 0),        # 1x1 filter
+    (1, 64, 64, 0, 64, 3, 0),
+    (2, 8, 512, 512, 512, 3, 0),       # the widest UNet layer
+    (5, 16, 256, 0, 384, 1, 0),        # to_qkv
+    (4, 32, 128, 0, 128, 3, 0),
+    (3, 5, 128, 0, 128, 3, 1),         # normalised-activation input; three samples inside one 64-position slice
+    (2, 64, 64, 0, 64, 3, 1),
+    (2, 16, 256, 0, 256, 3, 2),        # + SR3's additive embedding after the SiLU
 ])
-def test_weight_gradient_direct_from_nhwc(B, S, C0, C1, Cout, KT):
+def test_weight_gradient_direct_from_nhwc(B, S, C0, C1, Cout, KT, aff):
     """wgrad_direct_kernel (operands read as the forward left them, transposed LDS reads) against torch's conv2d weight gradient and
     the bias gradient against the pixel sum."""
     import ctypes as C
     P = C.c_void_p
-    fn = _dbg("hd_debug_conv_wgrad_direct", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, P])
+    fn = _dbg("hd_debug_conv_wgrad_direct", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, P, P, P, C.c_int, P])
     gen = torch.Generator().manual_seed(B * 1000 + S + KT)
     Cin = C0 + C1
     x = torch.randn((B, Cin, S, S), generator=gen)
     g = torch.randn((B, Cout, S, S), generator=gen) * 0.1
-    ref = torch.nn.grad.conv2d_weight(x, (Cout, Cin, KT, KT), g, padding=KT // 2)
+    A = torch.rand((B, Cin), generator=gen) + 0.5 if aff else None
+    Bv = torch.randn((B, Cin), generator=gen) * 0.3 if aff else None
+    E = torch.randn((B, Cin), generator=gen) * 0.5 if aff == 2 else None
+    xin = x
+    if aff:
+        xin = torch.nn.functional.silu(x * A[:, :, None, None] + Bv[:, :, None, None])
+        if aff == 2:
+            xin = xin + E[:, :, None, None]
+    ref = torch.nn.grad.conv2d_weight(xin, (Cout, Cin, KT, KT), g, padding=KT // 2)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
     x0, x1 = nhwc(x[:, :C0]), (nhwc(x[:, C0:]) if C1 else None)
     gd, out, db = nhwc(g), torch.empty((Cout, Cin, KT, KT), device="cuda"), torch.empty(Cout, device="cuda")
+    dev = lambda t: t.cuda().contiguous() if t is not None else None
+    Ad, Bd, Ed = dev(A), dev(Bv), dev(E)
     ptr = lambda t: P(t.data_ptr()) if t is not None else P()
-    rc = fn(ptr(x0), C0, ptr(x1), C1, ptr(gd), B, S, S, Cout, KT, ptr(out), ptr(db), P(torch.cuda.current_stream().cuda_stream))
+    rc = fn(ptr(x0), C0, ptr(x1), C1, ptr(gd), B, S, S, Cout, KT, ptr(out), ptr(db), ptr(Ad), ptr(Bd), ptr(Ed), 0, P(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     assert rel_err(ref, out) <= 1e-4
     assert rel_err(g.sum(dim=(0, 2, 3)), db) <= 1e-5
@@ -534,6 +547,7 @@ def test_resampling_layers_backward_components():
     from einops import rearrange
     P = C.c_void_p
     wg = _dbg("hd_debug_conv_wgrad", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, C.c_int, P, P])
+    wgd = _dbg("hd_debug_conv_wgrad_direct", [P, C.c_int, P, C.c_int, P] + [C.c_int] * 5 + [P, P, P, P, P, C.c_int, P])
     rs = _dbg("hd_debug_resample_bwd", [P] + [C.c_int] * 5 + [P, P])
     st = P(torch.cuda.current_stream().cuda_stream)
     nhwc = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
@@ -547,6 +561,9 @@ def test_resampling_layers_backward_components():
     xd, gd, out = nhwc(x), nhwc(g), torch.empty((Cout, Cc, 3, 3), device="cuda")
     assert wg(P(xd.data_ptr()), Cc, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 3, P(), P(), 2, P(out.data_ptr()), st) == 0
     assert rel_err(ref, out) <= 1e-4
+    out.zero_()                                                  # the same through the direct kernel's source addressing
+    assert wgd(P(xd.data_ptr()), Cc, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 3, P(out.data_ptr()), P(), P(), P(), P(), 1, st) == 0
+    assert rel_err(ref, out) <= 1e-4
     gup = torch.randn((B, Cc, H, H), generator=gen)
     up.backward(gup)
     gud, dx = nhwc(gup), torch.empty((B, H // 2, H // 2, Cc), device="cuda")
@@ -559,6 +576,9 @@ def test_resampling_layers_backward_components():
     ref = torch.nn.grad.conv2d_weight(un, (Cout, 4 * Cs, 1, 1), g)
     xd, out = nhwc(x), torch.empty((Cout, 4 * Cs, 1, 1), device="cuda")
     assert wg(P(xd.data_ptr()), 4 * Cs, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 1, P(), P(), 4, P(out.data_ptr()), st) == 0
+    assert rel_err(ref, out) <= 1e-4
+    out.zero_()
+    assert wgd(P(xd.data_ptr()), 4 * Cs, P(), 0, P(gd.data_ptr()), B, H, H, Cout, 1, P(out.data_ptr()), P(), P(), P(), P(), 2, st) == 0
     assert rel_err(ref, out) <= 1e-4
     gun = torch.randn((B, 4 * Cs, H, H), generator=gen)
     un.backward(gun)
