@@ -129,7 +129,7 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // M tiles with K in the thousands needs more workgroups, not bigger ones (unet40, 64 tiles: 4.54 -> 3.73 ms/step; measured
     // a loss from 8x8 upwards at 256 tiles).  By the map size only -- never by the batch.
     static const int narrow_max_hw = getenv("HICDIFF_NARROW_MAXHW") ? atoi(getenv("HICDIFF_NARROW_MAXHW")) : 63;
-    const bool wide = a.cw.CoutPad % 128 == 0 && a.H * a.W > narrow_max_hw;
+    const bool wide = a.cw.CoutPad % 128 == 0 && a.H * a.W > (a.narrow_max_hw > 0 ? a.narrow_max_hw : narrow_max_hw);
     pl.BN = wide ? 128 : 64;
     pl.BM = 128; pl.WM = 2; pl.cfg = wide ? 0 : 1;
     // 256 x 64 tile (waves 4 x 1) for 64-channel outputs on large feature maps.  The choice must not depend on

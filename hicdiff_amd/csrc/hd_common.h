@@ -69,6 +69,9 @@ struct ConvArgs {
     // split-K workspace (conv_splitk(a) * B*H*W*Cout floats) for the convolutions the planner splits; null: never split
     float* splitk_ws = nullptr;
     int plain_bf16 = 0;               // with precision == HD_PREC_BF16X3: drop the two correction products where a plain-bf16 variant exists (training option)
+    // N-tile rule override (0: the default): feature maps of at most this many pixels take 64-wide N tiles.  The training steps set 64
+    // (64 tiles per step: the 8x8 maps' 128-wide tiles fill a quarter of the chip; 28.1 -> 26.0 ms per UNet step); a rule by map size only.
+    int narrow_max_hw = 0;
     int precision = HD_PREC_F32;
 };
 

@@ -183,7 +183,9 @@ def main(argv=None):
         torch.save(diffusion.state_dict(), os.path.join(args.weights_dir, "final" + stem))      # train.py:189-190
     if args.print_checksum:
         flat = torch.cat([p.detach().reshape(-1).double() for p in diffusion.parameters()])
-        print(json.dumps({"rank": rank, "param_sum": float(flat.sum()), "param_abs_sum": float(flat.abs().sum())}), flush=True)
+        line = json.dumps({"rank": rank, "param_sum": float(flat.sum()), "param_abs_sum": float(flat.abs().sum())}) + "\n"
+        sys.stdout.flush()
+        os.write(sys.stdout.fileno(), line.encode())        # one write: ranks share the launcher's pipe, and a line must not interleave with another rank's
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
