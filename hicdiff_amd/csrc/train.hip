@@ -290,7 +290,7 @@ struct WgdArgs {
     int slices_per_split, total_slices, nsplit, Mtiles, Ntiles, M;
     float* partial; float* biaspart; int xcd_group;
     int src_mode;                                          // 0: X as [B][H][W][C]; 1: nearest x2 upsample of [B][H/2][W/2][C]; 2: pixel-unshuffle of [B][2H][2W][C/4]
-    const float* affA; const float* affB; const float* affE; int aff_bs;   // AFF kernels: X = silu(x * affA[b][c] + affB[b][c]) (+ affE[b][c])
+    const float* affA; const float* affB; const float* affE; int aff_bs; float aff_addA;   // AFF kernels: X = silu(x * (affA[b][c] + aff_addA) + affB[b][c]) (+ affE[b][c])
 };
 
 __device__ __forceinline__ uint2 split_quad(const float4& v, uint2& lo) {
@@ -309,12 +309,12 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int second) {      // 
 }
 
 // AFF: 0 = X as stored; 1 = a normalised activation recomputed on the way in, silu(x A + B) per (sample, channel); 2 = the same + E after
-// the SiLU (SR3's additive embedding).  The coefficients of each item travel with its prefetch (8-12 more registers per pixel), which
-// fits the 64-row tile only: AFF kernels are instantiated with TMW = 1.
+// the SiLU (SR3's additive embedding).  A thread keeps ONE coefficient set per channel quad, that of its first pixel's sample, requested
+// with the slice's prefetch; a pixel of another sample (a slice reaches into the next sample once per sample on large maps, in every
+// slice on 8 x 8 maps) fetches its own at store time.  affA == null: A = 1; aff_addA is added to A (FiLM's scale + 1).
 // SRC: source addressing of X (WgdArgs::src_mode) -- compiled in, the position arithmetic sits in the loop.
 template <bool ONE, int TMW, int AFF = 0, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
-    static_assert(AFF == 0 || TMW == 1, "the affine-input form uses the 64-row tile");
     // bytes per pixel row: the G image is padded (its taps are row offsets), the X image is XOR-swizzled instead (never shifted): 64-byte
     // chunk index ^= pixel & 3 (256-byte rows) or ^= (pixel >> 1) & 1 (128-byte rows)
     constexpr int BM = 64 * TMW, PX = BM * 2, PG = 64 * 2 + 64;
@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
         xch[t] = c;
     }
     float4 rX[4 * TMW], rG[4], rGh = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 cA[AFF ? 4 : 1], cB[AFF ? 4 : 1], cE[AFF == 2 ? 4 : 1];
+    float4 cA[TMW], cB[TMW], cE[TMW];
+    int s_first = 0; unsigned sdiff = 0;                                         // sample of pixel 0; (sample of pixel j) - s_first, 8 bits each
     unsigned vmask = 0;                                                          // bits 0-3: G item j valid; 4-7: X pixel j valid; 8: halo valid
     int sample = 0;
     auto locate = [&](int kp, int& gpix, bool& gv, int& xpix, bool& xv) {      // padded position -> source pixels
@@ -362,6 +363,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
         else if constexpr (SRC == 2) xpix = ((int)b * 2 * a.H + 2 * ys) * 2 * a.W + 2 * (int)xp;                  // top-left of the 2 x 2 source block
         else xpix = ((int)b * a.H + ys) * a.W + (int)xp;
         sample = in ? (int)b : 0;
+    };
+    struct Coef { float4 A, B, E; };
+    auto coef = [&](int smp, int t) __attribute__((always_inline)) {            // the (sample, quad t) coefficients
+        const size_t co = (size_t)smp * a.aff_bs + (xok[t] ? xch[t] : 0);
+        Coef c;
+        c.A = a.affA ? *reinterpret_cast<const float4*>(a.affA + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        c.A.x += a.aff_addA; c.A.y += a.aff_addA; c.A.z += a.aff_addA; c.A.w += a.aff_addA;
+        c.B = *reinterpret_cast<const float4*>(a.affB + co);
+        c.E = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (AFF == 2) c.E = *reinterpret_cast<const float4*>(a.affE + co);
+        return c;
     };
     auto request = [&](int s) {
         const int k0 = (s0 + s) * 64;
@@ -387,10 +399,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
             }
             vmask |= (xv ? 1u : 0u) << (4 + j);
             if constexpr (AFF != 0) {
-                const size_t co = (size_t)sample * a.aff_bs + (xok[0] ? xch[0] : 0);
-                cA[j] = *reinterpret_cast<const float4*>(a.affA + co);
-                cB[j] = *reinterpret_cast<const float4*>(a.affB + co);
-                if constexpr (AFF == 2) cE[j] = *reinterpret_cast<const float4*>(a.affE + co);
+                if (j == 0) {
+                    s_first = sample; sdiff = 0;
+#pragma unroll
+                    for (int t = 0; t < TMW; ++t) { const Coef c = coef(sample, t); cA[t] = c.A; cB[t] = c.B; cE[t] = c.E; }
+                } else {
+                    sdiff |= (unsigned)min(max(sample - s_first, 0), 255) << (8 * j);
+                }
             }
         }
         if (!ONE && tid < 32) {                                                  // the G halo: positions k0 - 1 and k0 + 64
@@ -416,9 +431,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
             for (int t = 0; t < TMW; ++t) {
                 float4 xq = rX[j * TMW + t];
                 if constexpr (AFF != 0) {
-                    xq = make_float4(silu_f(xq.x * cA[j].x + cB[j].x), silu_f(xq.y * cA[j].y + cB[j].y), silu_f(xq.z * cA[j].z + cB[j].z),
-                                     silu_f(xq.w * cA[j].w + cB[j].w));
-                    if constexpr (AFF == 2) { xq.x += cE[j].x; xq.y += cE[j].y; xq.z += cE[j].z; xq.w += cE[j].w; }
+                    float4 A = cA[t], Bc = cB[t], E = cE[t];
+                    const int dsm = (int)((sdiff >> (8 * j)) & 255u);
+                    if (dsm != 0) { const Coef c = coef(s_first + dsm, t); A = c.A; Bc = c.B; E = c.E; }   // a pixel of a later sample than the thread's first
+                    xq = make_float4(silu_f(xq.x * A.x + Bc.x), silu_f(xq.y * A.y + Bc.y), silu_f(xq.z * A.z + Bc.z), silu_f(xq.w * A.w + Bc.w));
+                    if constexpr (AFF == 2) { xq.x += E.x; xq.y += E.y; xq.z += E.z; xq.w += E.w; }
                 }
                 if (!(((vmask >> (4 + j)) & 1) && xok[t])) xq = zero4;           // zero padding applies to the transformed tensor
                 uint2 xl; const uint2 xh = split_quad(xq, xl);
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict_
             for (int j = 0; j < 8; ++j) a[j] += biaspart[(size_t)(sp + j) * Cout + co];
         }
         for (; sp < nsplit; ++sp) a[sp & 7] += biaspart[(size_t)sp * Cout + co];
-        db[co] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        db[co] = (accumulate ? db[co] : 0.f) + scale * (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
         return;
     }
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;          // over [KT][Mpad][KT*Cout]
@@ -879,10 +896,12 @@ struct Wgrad {
     // activations (x0 | x1) [B][H][W][C0 + C1], output gradient g [B][H][W][Cout]; dW in the torch layout, db (optional) [Cout]
     // affA / affB (/ affE), all [B][C0 + C1] or null: the input is silu(x affA + affB) (+ affE) per (sample, channel)
     int run_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, int KT, float* dW, float* db, hipStream_t st,
-                   const float* affA = nullptr, const float* affB = nullptr, const float* affE = nullptr, int src_mode = 0) const {
+                   const float* affA = nullptr, const float* affB = nullptr, const float* affE = nullptr, int src_mode = 0, float scale = 1.f,
+                   bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         const int Cin = C0 + C1;
-        const bool m64 = Cin <= 64 || affA;
+        const bool m64 = Cin <= 64;
+        const bool aff = affA || affB;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
         if (Cout % 64 || Cout > 1024 || C0 % 4 || C1 % 4 || (KT != 1 && KT != 3) || !x0 || (C1 && !x1)) { hd_set_error("wgrad (direct): unsupported shape"); return -1; }
         const long long Ktot = (long long)B * (H + 1) * (W + 1);
@@ -897,25 +916,26 @@ struct Wgrad {
         a.magicW = (unsigned)((1ull << 32) / (unsigned)(W + 1)) + 1u; a.magicH = (unsigned)((1ull << 32) / (unsigned)(H + 1)) + 1u;
         a.slices_per_split = sps; a.total_slices = total; a.nsplit = eff; a.Mtiles = Mt; a.Ntiles = Nt; a.M = Mpad;
         a.partial = partial; a.biaspart = db ? partial + (size_t)eff * per_split_floats : nullptr; a.xcd_group = xcd_group;
-        a.affA = affA; a.affB = affB; a.affE = affE; a.aff_bs = Cin; a.src_mode = src_mode;
-        if (src_mode && (C1 || affA || m64 || src_mode > 2 || (src_mode == 1 && (KT != 3 || ((H | W) & 1))) || (src_mode == 2 && KT != 1))) {
+        a.affA = affA; a.affB = affB; a.affE = affE; a.aff_bs = aff_bs > 0 ? aff_bs : Cin; a.aff_addA = aff_addA; a.src_mode = src_mode;
+        if (src_mode && (C1 || aff || m64 || src_mode > 2 || (src_mode == 1 && (KT != 3 || ((H | W) & 1))) || (src_mode == 2 && KT != 1))) {
             hd_set_error("wgrad (direct): unsupported source addressing");
             return -1;
         }
-        if (affA && (!affB || KT != 3)) { hd_set_error("wgrad (direct): the affine-input form is the 3 x 3 one and needs both coefficient arrays"); return -1; }
+        if (aff && (!affB || KT != 3)) { hd_set_error("wgrad (direct): the affine-input form is the 3 x 3 one and needs the shift array"); return -1; }
         const char* name = KT == 1 ? "wgrad_direct_kernel<true>" : "wgrad_direct_kernel<false>";
         hd_prof_begin(name, 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
         const dim3 grid(Mt * Nt * eff, ndy);
         if (src_mode == 1) hipLaunchKernelGGL((wgrad_direct_kernel<false, 2, 0, 1>), grid, dim3(256), 0, st, a);
         else if (src_mode == 2) hipLaunchKernelGGL((wgrad_direct_kernel<true, 2, 0, 2>), grid, dim3(256), 0, st, a);
         else if (KT == 1) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<true, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<true, 2>), grid, dim3(256), 0, st, a); }
-        else if (affA) { if (affE) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 1>), grid, dim3(256), 0, st, a); }
+        else if (aff && affE) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 2>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2, 2>), grid, dim3(256), 0, st, a); }
+        else if (aff) { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2, 1>), grid, dim3(256), 0, st, a); }
         else { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2>), grid, dim3(256), 0, st, a); }
         conv_prof_end(st);
         if (check_launch("wgrad direct")) return -3;
         const int nmain = (int)((per_split_floats + 255) / 256);
-        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)(nmain + (db ? (Cout + 255) / 256 : 0))), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, 1.f, 0, dW,
-                           a.biaspart, db, nmain);
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)(nmain + (db ? (Cout + 255) / 256 : 0))), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, scale,
+                           accumulate ? 1 : 0, dW, a.biaspart, db, nmain);
         return check_launch("wg_reduce");
     }
     // dW[Cout][Cin][KT][KT] (+)= scale * sum over pixels (activation image rows 0..Cin-1, gradient image rows 0..Cout-1)
@@ -1233,10 +1253,17 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     float* dY = tr->g1;
     TR_TRY(launch_conv_small_cin(tr->dout, nullptr, tr->tail_flip, tr->zero_bias, dY, B, S, 3, 1, F, st));
     // body_tail: dX_n = dgrad(dY); dW = wgrad(X_n, dY); the skip r sends dY to the head output as well
-    TR_TRY(prep(tr, tr->X[n], false, 0, nullptr, nullptr, st));
-    TR_TRY(prep(tr, dY, true, 0, nullptr, tr->colpart, st));
-    TR_TRY(wgrad(tr, 1.f, false, grads + tr->o_conv_w[n], st));
-    TR_TRY(colsum(tr, 1.f, false, grads + tr->o_conv_b[n], st));
+    // weight gradients: straight from the NHWC tensors (wgrad_direct_kernel) in the default arithmetic; operand rewrite + GEMM for plain bf16
+    static const bool no_direct = getenv("HICDIFF_WG_NODIRECT") != nullptr;
+    const bool direct = !tr->plain && !no_direct;
+    if (direct) {
+        TR_TRY(tr->wg.run_direct(tr->X[n], F, nullptr, 0, dY, F, 3, grads + tr->o_conv_w[n], grads + tr->o_conv_b[n], st));
+    } else {
+        TR_TRY(prep(tr, tr->X[n], false, 0, nullptr, nullptr, st));
+        TR_TRY(prep(tr, dY, true, 0, nullptr, tr->colpart, st));
+        TR_TRY(wgrad(tr, 1.f, false, grads + tr->o_conv_w[n], st));
+        TR_TRY(colsum(tr, 1.f, false, grads + tr->o_conv_b[n], st));
+    }
     float* dx = tr->g2;                       // gradient w.r.t. the current block output
     float* da = tr->g0;
     TR_TRY(conv3(tr, tr->bwd[n], dY, dx, 0, 1.f, nullptr, st));
@@ -1246,19 +1273,27 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         float* dW = grads + tr->o_conv_w[i];
         float* db = grads + tr->o_conv_b[i];
         // second use of the conv: y = 0.1 conv(a) + x
-        TR_TRY(prep(tr, tr->U[i], false, 1, film, nullptr, st));                 // a = silu(film(u)), recomputed
-        TR_TRY(prep(tr, dx, true, 0, nullptr, tr->colpart, st));
-        TR_TRY(wgrad(tr, 0.1f, false, dW, st));
-        TR_TRY(colsum(tr, 0.1f, false, db, st));
+        if (direct) {                                                            // a = silu(u (scale + 1) + shift), recomputed in the loader (FW == F: shift only)
+            TR_TRY(tr->wg.run_direct(tr->U[i], F, nullptr, 0, dx, F, 3, dW, db, st, FW > F ? film : nullptr, film + (FW - F), nullptr, 0, 0.1f, false, FW, 1.f));
+        } else {
+            TR_TRY(prep(tr, tr->U[i], false, 1, film, nullptr, st));                 // a = silu(film(u)), recomputed
+            TR_TRY(prep(tr, dx, true, 0, nullptr, tr->colpart, st));
+            TR_TRY(wgrad(tr, 0.1f, false, dW, st));
+            TR_TRY(colsum(tr, 0.1f, false, db, st));
+        }
         TR_TRY(conv3(tr, tr->bwd[i], dx, da, 0, 1.f, nullptr, st));              // dL/da / 0.1
         hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, FW, HW, F, 64, 0.1f, tr->fpart);
         hipLaunchKernelGGL(sum_rows_kernel, dim3((FW + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, FW, 1.f, 0, tr->dfilm + (size_t)i * B * FW);
         TR_TRY(check_launch("film_silu_bwd"));
         // first use: u = conv(x)
-        TR_TRY(prep(tr, tr->X[i], false, 0, nullptr, nullptr, st));
-        TR_TRY(prep(tr, da, true, 0, nullptr, tr->colpart, st));
-        TR_TRY(wgrad(tr, 1.f, true, dW, st));
-        TR_TRY(colsum(tr, 1.f, true, db, st));
+        if (direct) {
+            TR_TRY(tr->wg.run_direct(tr->X[i], F, nullptr, 0, da, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 1.f, true));
+        } else {
+            TR_TRY(prep(tr, tr->X[i], false, 0, nullptr, nullptr, st));
+            TR_TRY(prep(tr, da, true, 0, nullptr, tr->colpart, st));
+            TR_TRY(wgrad(tr, 1.f, true, dW, st));
+            TR_TRY(colsum(tr, 1.f, true, db, st));
+        }
         float* nxt = (dx == tr->g2) ? tr->Y : tr->g2;                            // Y is free once its gradients are taken; g1 keeps dY
         TR_TRY(conv3(tr, tr->bwd[i], da, nxt, EP_RES, 1.f, dx, st));            // dx_i = dgrad(du) + dx_{i+1}
         dx = nxt;
