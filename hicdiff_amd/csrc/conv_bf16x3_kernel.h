@@ -42,6 +42,13 @@
 #define ABL(bit) false
 #endif
 
+// make EXTRA=-DHD_STAMPS: wave 0 of every workgroup below 4096 leaves cycle stamps (start, loop entry, loop exit, end, cycles spent in the
+// loop's barriers, XCC / CU id) in a device array that tools/conv_probe.py prints -- a timing study, never part of the product build.
+#ifdef HD_STAMPS
+static __device__ unsigned long long g_conv_stamps[4096][6];
+#define HD_STAMP() __builtin_readcyclecounter()
+#endif
+
 enum { IN_AFFINE_SILU_E = 3 };   // kernel-side mode: IN_AFFINE_SILU with the additive term inE (SR3 blocks)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -128,6 +135,10 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     char* Xs = Ws + 2 * SLAB;                          // [1 or 2][npx + 1][PITCH]; row npx is a write sink
     const int xs_stride = XDB ? p.xs_stride : 0;
 
+#ifdef HD_STAMPS
+    const unsigned long long st_begin = HD_STAMP();
+    unsigned long long st_bar = 0;
+#endif
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
     // split-K (3x3 only): grid.y picks a run of K slices; this workgroup writes its raw sums to its own slab of the workspace
@@ -344,6 +355,9 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         }
     }
 
+#ifdef HD_STAMPS
+    const unsigned long long st_loop = HD_STAMP();
+#endif
     int buf = 0;
     if constexpr (NTAPS == 9) {
         // One tap of the main loop, tap index known at compile time.  NEXT: a next slice exists (slices
@@ -352,7 +366,13 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
             constexpr int tap = decltype(tapc)::value;
             constexpr bool NEXT = decltype(has_next)::value;
             using SN = std::integral_constant<int, (tap + 1) % WD>;
+#ifdef HD_STAMPS
+            const unsigned long long b0 = HD_STAMP();
+#endif
             __syncthreads();             // slab `it` and the window of slice c are visible; nobody still reads slab it-1
+#ifdef HD_STAMPS
+            st_bar += HD_STAMP() - b0;
+#endif
             // slab it+1 (set (tap+1) % WD) -> LDS, then slab it+1+WD is requested into the set just freed
             if constexpr (NEXT || tap + 1 < 9) w_store(SN{}, buf ^ 1);
             if constexpr (tap + 1 + WD < 9) w_load(SN{}, c, tap + 1 + WD);
@@ -442,7 +462,20 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     (void)w1; (void)w2; (void)w3; (void)v0; (void)v1; (void)v2; (void)v3; (void)u0; (void)u1; (void)u2; (void)u3; (void)pr1; (void)pr2;
 #undef HD_WLOAD
 #undef HD_WSTORE
+#ifdef HD_STAMPS
+    const unsigned long long st_epi = HD_STAMP();
+#endif
     conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(ptab));
+#ifdef HD_STAMPS
+    if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* g = g_conv_stamps[blockIdx.x];
+        g[0] = st_begin; g[1] = st_loop; g[2] = st_epi; g[3] = HD_STAMP(); g[4] = st_bar; g[5] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 }
 
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
