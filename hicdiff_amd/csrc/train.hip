@@ -313,6 +313,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int second) {      // 
 // with the slice's prefetch; a pixel of another sample (a slice reaches into the next sample once per sample on large maps, in every
 // slice on 8 x 8 maps) fetches its own at store time.  affA == null: A = 1; aff_addA is added to A (FiLM's scale + 1).
 // SRC: source addressing of X (WgdArgs::src_mode) -- compiled in, the position arithmetic sits in the loop.
+#ifdef HD_STAMPS
+__device__ unsigned long long g_wgd_stamps[1024][4];      // per workgroup (wave 0): cycles in the store phase (incl. the wait for the prefetched loads), in barriers, in the MFMA phase, total
+#endif
 template <bool ONE, int TMW, int AFF = 0, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
     // bytes per pixel row: the G image is padded (its taps are row offsets), the X image is XOR-swizzled instead (never shifted): 64-byte
@@ -471,10 +474,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][x][r] = 0.f;
 
+#ifdef HD_STAMPS
+    unsigned long long c_store = 0, c_bar = 0, c_mma = 0, t0, t1;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
     request(0);
     for (int s = 0; s < nslices; ++s) {
+#ifdef HD_STAMPS
+        t0 = __builtin_readcyclecounter();
+#endif
         store();
+#ifdef HD_STAMPS
+        t1 = __builtin_readcyclecounter(); c_store += t1 - t0;
+#endif
         __syncthreads();
+#ifdef HD_STAMPS
+        t0 = __builtin_readcyclecounter(); c_bar += t0 - t1;
+#endif
         request(min(s + 1, nslices - 1));
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -498,8 +514,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
                 }
             }
         }
+#ifdef HD_STAMPS
+        t1 = __builtin_readcyclecounter(); c_mma += t1 - t0;
+#endif
         __syncthreads();
+#ifdef HD_STAMPS
+        c_bar += __builtin_readcyclecounter() - t1;
+#endif
     }
+#ifdef HD_STAMPS
+    if (tid == 0 && blockIdx.x < 1024 && blockIdx.y == 0) {
+        g_wgd_stamps[blockIdx.x][0] = c_store; g_wgd_stamps[blockIdx.x][1] = c_bar; g_wgd_stamps[blockIdx.x][2] = c_mma;
+        g_wgd_stamps[blockIdx.x][3] = __builtin_readcyclecounter() - t_begin;
+    }
+#endif
     const int N = NDX * a.F;
     float* out = a.partial + ((size_t)(split * NDX + (ONE ? 0 : dyi)) * a.M) * N;
 #pragma unroll
@@ -1429,6 +1457,12 @@ extern "C" int hd_debug_conv_wgrad_direct(const float* x0, int C0, const float* 
     wg.destroy();
     return rc ? HD_EHIP : HD_OK;
 }
+
+#ifdef HD_STAMPS
+extern "C" int hd_debug_wgd_stamps(unsigned long long* out, int nwg) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgd_stamps), sizeof(unsigned long long) * 4 * nwg) == hipSuccess ? 0 : -3;
+}
+#endif
 
 // ---- test-only entry (include/hicdiff_hip_debug.h): the weight-gradient component on arbitrary shapes ---------------------------
 extern "C" int hd_debug_conv_wgrad(const float* x0, int C0, const float* x1, int C1, const float* g, int B, int H, int W, int Cout, int KT, const float* affA,
