@@ -148,8 +148,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     }
     if (p.stagger) {
         const int mode = p.stagger >> 16, n = p.stagger & 0xffff, b = blockIdx.x;
-        const bool hit = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : (b >> 3) & 1);
-        if (hit) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        if (mode == 4) {
+            // sixteen start phases spread over the first round (the workgroups of an XCD are b = xcd + 8 j): j and j + 32 -- the two slots
+            // of a CU if the dispatcher fills the CUs in order -- half a cycle apart; n = cycles / 64 of one phase step
+            const int j = b >> 3, phase = (j + ((j >> 5) & 1) * 8) & 15;
+            if (b < 512) for (int i = 0; i < phase * n; ++i) __builtin_amdgcn_s_sleep(1);
+        } else {
+            const bool hit = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : (b >> 3) & 1);
+            if (hit) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+        }
     }
 
     // ---- parameter table: thread tid < n4 owns entry tid = (sample tid / (CK/4), channels 4 * (tid % (CK/4)))

@@ -157,6 +157,9 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 //   stage: LDS, BM x (BN + 4) floats, overlays the operand buffers (all MFMA reads are done).
 //   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
 //   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
+#ifdef HD_STAMPS
+static __device__ unsigned long long g_conv_epi_stamps[4096][3];   // per workgroup (wave 0), cycles inside the epilogue's barriers / LDS staging writes / row passes with their stores
+#endif
 template <int BM, int BN, int TM, int TN, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
                                               const int* rowb, float* stage) {
@@ -169,16 +172,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
     const bool vec = nvalid >= 4 && (p.Cout & 3) == 0;
     float bias[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
+        if (vec) {     // one 16-byte load, requested here and first used after the staging round (four guarded scalar loads sat behind a vmcnt(0) right here)
+            const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+            bias[0] = b4.x; bias[1] = b4.y; bias[2] = b4.z; bias[3] = b4.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (j < nvalid) bias[j] = p.bias[n + j];
+            for (int j = 0; j < 4; ++j) if (j < nvalid) bias[j] = p.bias[n + j];
+        }
     }
     // GroupNorm partial sums of this lane's 4 channels.  Two sets: with two whole 8x8 images per tile (TB == 2, BM == 128)
     // rows 0..63 belong to sample b0 and rows 64..127 to b0+1, i.e. the upper half of every staging round (lr >= 32).
     float s1[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, s2[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const bool two = p.TB == 2;
+#ifdef HD_STAMPS
+    unsigned long long e_bar = 0, e_stage = 0, e_store = 0, e0, e1;
+#endif
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+#ifdef HD_STAMPS
+        e0 = __builtin_readcyclecounter();
+#endif
         __syncthreads();                   // operands (tm == 0) / previous round's rows are no longer read
+#ifdef HD_STAMPS
+        e1 = __builtin_readcyclecounter(); e_bar += e1 - e0;
+#endif
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int col = t.wn * 32 * TN + tn * 32 + t.l31;
@@ -188,7 +205,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 stage[lr * EP + col] = acc[tm][tn][r];
             }
         }
+#ifdef HD_STAMPS
+        e0 = __builtin_readcyclecounter(); e_stage += e0 - e1;
+#endif
         __syncthreads();
+#ifdef HD_STAMPS
+        e1 = __builtin_readcyclecounter(); e_bar += e1 - e0;
+#endif
         if (nvalid > 0 && !(p.ablate & 128)) {
             if (p.ep & EP_LN_RES) {
                 // Whole rows live in this workgroup (Cout == BN, checked by the launcher): channel LayerNorm of the
@@ -226,17 +249,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 // Fast path (every GroupNorm'd conv): no global load in the loop.  vmcnt retires in issue order, so a
                 // loop that mixes loads with stores makes every load wait for the previous pass's STORE round trip
                 // (measured: half of the kernel on the 64-channel full-resolution layers); here stores just stream.
+                // All passes' LDS reads (row -> pixel table, staged row) are issued first: read one pass at a time, behind
+                // the previous pass's guarded store, every pass paid two exposed LDS round trips (HD_STAMPS: 640 cycles per pass, 10 k of a
+                // 14 k-cycle epilogue on the 64-channel layers; skipping the stores altogether changed nothing).
+                // (A further split of this loop into a one-sample form without the upper / lower-half selects measured another -1.1 % per
+                // step but made an 8x8 map's result depend on which half of the tile the sample sits in -- tile results must not depend on
+                // the batch, tests/test_gpu_parity.py::test_batch_independence_and_determinism_full_size -- and was dropped.)
+                int pixs[NPASS];
+                float4 rows[NPASS];
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     const int lr = pass * RPP + rg;
-                    const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
-                    const int pix = rowpix[m];
+                    pixs[pass] = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
+                    rows[pass] = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                }
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    const int lr = pass * RPP + rg;
+                    const int pix = pixs[pass];
                     const bool up = two && lr >= 32;
-                    const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
+                    const float4 a4 = rows[pass];
                     const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
                     if (pix >= 0) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {   // selects, not indexing: a dynamically indexed register array goes to scratch
+                        for (int j = 0; j < 4; ++j) {
                             const float x = o4[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
                             s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
                         }
@@ -356,6 +392,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 }
             }
         }
+#ifdef HD_STAMPS
+        e_store += __builtin_readcyclecounter() - e1;
+#endif
     }
     (void)WMN;
     if (p.gn_part) {   // TB == 1: every row of this workgroup belongs to sample b0; TB == 2 (two 8x8 images): a second set
@@ -377,6 +416,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
             }
         }
     }
+#ifdef HD_STAMPS
+    if (t.tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
+        g_conv_epi_stamps[blockIdx.x][0] = e_bar; g_conv_epi_stamps[blockIdx.x][1] = e_stage; g_conv_epi_stamps[blockIdx.x][2] = e_store;
+    }
+#endif
 }
 
 // host-side launch record shared by the two kernel files

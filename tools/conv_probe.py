@@ -65,6 +65,11 @@ def main():
             print(f"  stamps over {len(sa)} workgroups (cycles of wave 0, mean / p10 / p90): prologue {pro.mean():.0f} / {np.percentile(pro, 10):.0f} / {np.percentile(pro, 90):.0f}"
                   f"   loop {loop.mean():.0f} / {np.percentile(loop, 10):.0f} / {np.percentile(loop, 90):.0f} (of which in barriers {bar.mean():.0f})"
                   f"   epilogue {epi.mean():.0f} / {np.percentile(epi, 10):.0f} / {np.percentile(epi, 90):.0f}")
+            ebuf = (C.c_ulonglong * (3 * nwg))()
+            if hasattr(lib, "hd_debug_conv_epi_stamps") and lib.hd_debug_conv_epi_stamps(ebuf, nwg) == 0:
+                e = np.frombuffer(ebuf, dtype=np.uint64).reshape(nwg, 3).astype(np.int64)
+                e = e[e.sum(axis=1) > 0]
+                print(f"  inside the epilogue (mean cycles): barriers {e[:, 0].mean():.0f}, accumulators -> LDS {e[:, 1].mean():.0f}, row passes + stores {e[:, 2].mean():.0f}")
             # timeline of a few CUs (a CU's workgroups share a cycle counter; HW_ID bits 8-15 = CU / SH / SE): start, loop entry,
             # epilogue entry and end of each of its workgroups, in thousands of cycles from the CU's first start
             key = ((sa[:, 5] >> 32) << 8) | ((sa[:, 5] & 0xffff) >> 8)
