@@ -552,6 +552,214 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
     }
 }
 
+// ---- all nine taps in one workgroup over a rolling window of activation positions ------------------------------------------------
+// wgrad_direct_kernel gives each row tap its own workgroup: the gradient slice is staged three times and every activation position
+// three times (once per row tap that touches it) -- 49 KB of operands per 72 MFMAs of a wave.  Here a workgroup of EIGHT waves (one per
+// CU: 128 input channels x 64 output channels x 9 taps, 9 accumulator tiles per wave) keeps the activation positions
+// [k0 - (W+1), k0 + 63 + (W+1)] of the padded position space resident in an LDS ring (R = 128 or 256 positions, index = position & (R-1))
+// and adds the 64 new positions of each slice: in the padded space the row tap is the position offset (ky-1)(W+1) -- the zero row
+// between samples and the zero column between rows make every out-of-map neighbour a stored zero -- so the A fragments of the three
+// row taps are three transposed reads of the same ring, and each activation is loaded from memory ONCE per workgroup: 49 KB per
+// 108 MFMAs of each of 8 waves.  Column taps, fragment reads, splitting, bias sums and the partial layout are wgrad_direct_kernel's.
+// AFF as there (0 / 1 / 2).  Layers with more than 64 input channels, 3 x 3 filters, plain source addressing.
+template <int AFF>
+__global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
+    constexpr int PX = 256, PG = 64 * 2 + 64;                                    // bytes per position: 128 channels (swizzled) / 64 channels + pad
+    extern __shared__ __attribute__((aligned(16))) char smem9[];
+    char* const XHI = smem9; char* const XLO = XHI + (size_t)R * PX;
+    char* const GHI = XLO + (size_t)R * PX; char* const GLO = GHI + 66 * PG;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int wm = w >> 1, wn = w & 1;                                           // 4 x 2 waves of 32 x 32 (x 9 taps)
+    const int per = a.Mtiles * a.Ntiles;
+    int split, inner;
+    if ((a.nsplit & 7) == 0 && a.xcd_group) { const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3; split = xcd + 8 * (j / per); inner = j % per; }
+    else { split = blockIdx.x / per; inner = blockIdx.x % per; }
+    const int nt = inner % a.Ntiles, mt = inner / a.Ntiles;
+    const int Wp = a.W + 1, Hp = a.H + 1, Ktot = a.B * Hp * Wp, Cin = a.C0 + a.C1, RM = R - 1;
+    const int s0 = split * a.slices_per_split;
+    const int nslices = min(a.slices_per_split, a.total_slices - s0);
+    const bool do_bias = a.biaspart != nullptr && mt == 0;
+
+    // ---- loader roles.  X: positions xp0 + 16 j (j < 4) of a 64-position chunk, channel quad xq (32 quads = 128 channels);
+    // G: positions gp0 + 32 j (j < 2), channel quad gq (16 quads); threads 0..31 also carry the two halo positions of G.
+    const int xp0 = tid >> 5, xq = tid & 31, gp0 = tid >> 4, gq = tid & 15;
+    const int gch = nt * 64 + gq * 4;
+    const int xc = mt * 128 + xq * 4;
+    const bool xok = xc < Cin;
+    const float* xsrc; int xC;
+    if (xc < a.C0) { xsrc = a.x0 + xc; xC = a.C0; } else { xsrc = a.x1 + (xc - a.C0); xC = a.C1; }
+    if (!xok) { xsrc = a.x0; xC = a.C0; }
+    auto locate = [&](int kp, int& pix, int& smp) {                               // padded position -> source pixel (or -1) and sample
+        const bool in = kp >= 0 && kp < Ktot;
+        const unsigned k = in ? (unsigned)kp : 0u;
+        const unsigned yq = __umulhi(k, a.magicW), xp = k - yq * Wp, b = __umulhi(yq, a.magicH), yp = yq - b * Hp;
+        pix = in && (int)xp < a.W && (int)yp < a.H ? ((int)b * a.H + (int)yp) * a.W + (int)xp : -1;
+        smp = in ? (int)b : 0;
+    };
+    struct Coef { float4 A, B, E; };
+    auto coef = [&](int smp) __attribute__((always_inline)) {
+        const size_t co = (size_t)smp * a.aff_bs + (xok ? xc : 0);
+        Coef c;
+        c.A = a.affA ? *reinterpret_cast<const float4*>(a.affA + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        c.A.x += a.aff_addA; c.A.y += a.aff_addA; c.A.z += a.aff_addA; c.A.w += a.aff_addA;
+        c.B = *reinterpret_cast<const float4*>(a.affB + co);
+        c.E = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (AFF == 2) c.E = *reinterpret_cast<const float4*>(a.affE + co);
+        return c;
+    };
+    float4 rX[4], rG[2], rGh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cA = make_float4(1.f, 1.f, 1.f, 1.f), cB = make_float4(0.f, 0.f, 0.f, 0.f), cE = cB;
+    int s_first = 0; unsigned sdiff = 0, vmask = 0;                              // vmask bits 0-3: X item valid; 4-5: G item; 6: halo
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bsum = zero4;
+    // X chunk = the 64 positions starting at P; request / write are separate so that a chunk travels in registers under the MFMAs
+    auto x_request = [&](int P) {
+        vmask &= ~0xfu; sdiff = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int pix, smp;
+            locate(P + xp0 + 16 * j, pix, smp);
+            rX[j] = *reinterpret_cast<const float4*>(xsrc + (size_t)(pix < 0 ? 0 : pix) * xC);
+            vmask |= (pix >= 0 ? 1u : 0u) << j;
+            if constexpr (AFF != 0) {
+                if (j == 0) { s_first = smp; const Coef c = coef(smp); cA = c.A; cB = c.B; cE = c.E; }
+                else sdiff |= (unsigned)min(max(smp - s_first, 0), 255) << (8 * j);
+            }
+        }
+    };
+    auto x_write = [&](int P) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pos = P + xp0 + 16 * j;
+            float4 xq4 = rX[j];
+            if constexpr (AFF != 0) {
+                float4 A = cA, Bc = cB, E = cE;
+                const int dsm = (int)((sdiff >> (8 * j)) & 255u);
+                if (dsm != 0) { const Coef c = coef(s_first + dsm); A = c.A; Bc = c.B; E = c.E; }
+                xq4 = make_float4(silu_f(xq4.x * A.x + Bc.x), silu_f(xq4.y * A.y + Bc.y), silu_f(xq4.z * A.z + Bc.z), silu_f(xq4.w * A.w + Bc.w));
+                if constexpr (AFF == 2) { xq4.x += E.x; xq4.y += E.y; xq4.z += E.z; xq4.w += E.w; }
+            }
+            if (!(((vmask >> j) & 1) && xok)) xq4 = zero4;
+            uint2 lo; const uint2 hi = split_quad(xq4, lo);
+            const int o = (pos & RM) * PX + ((xq * 8) ^ ((pos & 3) << 6));
+            *reinterpret_cast<uint2*>(XHI + o) = hi;
+            *reinterpret_cast<uint2*>(XLO + o) = lo;
+        }
+    };
+    auto g_request = [&](int k0) {
+        vmask &= 0xfu;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            int pix, smp;
+            locate(k0 + gp0 + 32 * j, pix, smp);
+            rG[j] = *reinterpret_cast<const float4*>(a.g + (size_t)(pix < 0 ? 0 : pix) * a.F + gch);
+            vmask |= (pix >= 0 ? 1u : 0u) << (4 + j);
+        }
+        if (tid < 32) {
+            int pix, smp;
+            locate(tid < 16 ? k0 - 1 : k0 + 64, pix, smp);
+            rGh = *reinterpret_cast<const float4*>(a.g + (size_t)(pix < 0 ? 0 : pix) * a.F + gch);
+            vmask |= (pix >= 0 ? 1u : 0u) << 6;
+        }
+    };
+    auto g_write = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float4 g4 = (vmask >> (4 + j)) & 1 ? rG[j] : zero4;
+            if (do_bias) { bsum.x += g4.x; bsum.y += g4.y; bsum.z += g4.z; bsum.w += g4.w; }
+            uint2 lo; const uint2 hi = split_quad(g4, lo);
+            const int o = (gp0 + 32 * j + 1) * PG + gq * 8;
+            *reinterpret_cast<uint2*>(GHI + o) = hi;
+            *reinterpret_cast<uint2*>(GLO + o) = lo;
+        }
+        if (tid < 32) {
+            const float4 g4 = (vmask >> 6) & 1 ? rGh : zero4;
+            uint2 lo; const uint2 hi = split_quad(g4, lo);
+            const int o = (tid < 16 ? 0 : 65) * PG + gq * 8;
+            *reinterpret_cast<uint2*>(GHI + o) = hi;
+            *reinterpret_cast<uint2*>(GLO + o) = lo;
+        }
+    };
+
+    // ---- fragment addresses (lane 4q + p of 16-lane group: position row q, channels 4p .. 4p+3 of its block)
+    const int grp = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+    const int prow = 8 * (grp >> 1) + q4;
+    const int xchb = (wm * 32 + 16 * (grp & 1) + 4 * p4) * 2;                    // byte offset of this lane's channels in an X position row
+    const int goff = (prow + 1) * PG + (wn * 32 + 16 * (grp & 1) + 4 * p4) * 2;
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int y = 0; y < 3; ++y)
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[y][x][r] = 0.f;
+
+    // ---- prologue: the ring holds [k0 - Wp, k0 + Wp) before slice 0 adds [k0 + Wp, k0 + Wp + 64)
+    const int kbeg = s0 * 64;
+    {
+        const int nlead = (2 * Wp + 63) >> 6;                                    // whole chunks that cover the 2 Wp leading positions
+        for (int c = nlead; c >= 1; --c) {
+            x_request(kbeg + Wp - 64 * c);
+            x_write(kbeg + Wp - 64 * c);
+        }
+    }
+    x_request(kbeg + Wp);
+    g_request(kbeg);
+    for (int s = 0; s < nslices; ++s) {
+        const int k0 = kbeg + 64 * s;
+        x_write(k0 + Wp);
+        g_write();
+        __syncthreads();
+        { const int sn = min(s + 1, nslices - 1); x_request(kbeg + 64 * sn + Wp); g_request(kbeg + 64 * sn); }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bh[3], bl[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {                                     // kx = dx: G[k + 1 - kx]
+                bh[dx] = tr_read8(GHI + goff + ks * 16 * PG + (1 - dx) * PG, 4 * PG);
+                bl[dx] = tr_read8(GLO + goff + ks * 16 * PG + (1 - dx) * PG, 4 * PG);
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {                                     // ky = dy: X[k + (ky - 1) Wp], two 4-position blocks
+                const int p0 = k0 + (dy - 1) * Wp + ks * 16 + prow, p1 = p0 + 4;
+                const int o0 = (p0 & RM) * PX + (xchb ^ ((p0 & 3) << 6)), o1 = (p1 & RM) * PX + (xchb ^ ((p1 & 3) << 6));
+                const bf16x8 ah = tr_read8(XHI + o0, o1 - o0), al = tr_read8(XLO + o0, o1 - o0);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[dx], acc[dy][dx], 0, 0, 0);
+                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[dx], acc[dy][dx], 0, 0, 0);
+                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[dx], acc[dy][dx], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const int N = 3 * a.F;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        float* out = a.partial + ((size_t)(split * 3 + dy) * a.M) * N;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 128 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int n = dx * a.F + nt * 64 + wn * 32 + l31;
+                out[(size_t)m * N + n] = acc[dy][dx][r];
+            }
+    }
+    if (do_bias) {                                                               // uniform per workgroup
+        float* red = reinterpret_cast<float*>(smem9);                           // [32 position groups][64 channels]
+        *reinterpret_cast<float4*>(red + gp0 * 64 + gq * 4) = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+            for (int k = 0; k < 32; ++k) t += red[k * 64 + tid];
+            a.biaspart[(size_t)split * a.F + nt * 64 + tid] = t;
+        }
+    }
+}
+
 // dW[co][ci][ky][kx] (torch layout, KT x KT taps, KT = 3 or 1) (+)= scale * sum_split partial[split][ky][ci (< Mpad)][kx*Cout + co]
 __global__ __launch_bounds__(256) void wg_reduce_kernel(const float* __restrict__ partial, int nsplit, int Cin, int Mpad, int Cout, int KT, float scale,
                                                         int accumulate, float* __restrict__ dW, const float* __restrict__ biaspart = nullptr,
@@ -908,9 +1116,9 @@ struct Wgrad {
     // 16x16 / 8x8 maps: 64-128 workgroups on 256 CUs, each looping over the three row taps.)  Measured (MI355X, 64 tiles): the UNet's
     // layers (1-12 tiles per split) are fastest with ONE round of 512 workgroups (39.0 ms per step; 40.7-40.8 at 256 / 768 / 1024),
     // hicedrn's 24-tile layers with 960 (0.96 ms per GEMM; 1.02 at 384).
-    int pick_splits(int tiles, int total_slices, size_t per_split_floats, int* slices_per_split) const {
+    int pick_splits(int tiles, int total_slices, size_t per_split_floats, int* slices_per_split, int want = 0) const {
         static const int target_env = getenv("HICDIFF_WG_TARGET") ? atoi(getenv("HICDIFF_WG_TARGET")) : 0;
-        const int target = target_env ? target_env : (tiles >= 16 ? 1024 : 512);
+        const int target = want ? want : target_env ? target_env : (tiles >= 16 ? 1024 : 512);
         int eff = std::max(1, target / tiles);
         eff = std::min<int>(eff, std::max(1, total_slices / 8));
         eff = (int)std::min<size_t>((size_t)eff, partial_floats / (per_split_floats + 1024));   // + room for a bias row per split
@@ -928,6 +1136,7 @@ struct Wgrad {
                    bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         const int Cin = C0 + C1;
+        if (direct9_ok(Cin, W, KT, src_mode, false)) return run_direct9(x0, C0, x1, C1, g, Cout, dW, db, st, affA, affB, affE, scale, accumulate, aff_bs, aff_addA);
         const bool m64 = Cin <= 64;
         const bool aff = affA || affB;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
@@ -961,6 +1170,51 @@ struct Wgrad {
         else { if (m64) hipLaunchKernelGGL((wgrad_direct_kernel<false, 1>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((wgrad_direct_kernel<false, 2>), grid, dim3(256), 0, st, a); }
         conv_prof_end(st);
         if (check_launch("wgrad direct")) return -3;
+        const int nmain = (int)((per_split_floats + 255) / 256);
+        hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)(nmain + (db ? (Cout + 255) / 256 : 0))), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, scale,
+                           accumulate ? 1 : 0, dW, a.biaspart, db, nmain);
+        return check_launch("wg_reduce");
+    }
+    // the nine-tap form (wgrad_direct9_kernel: one 8-wave workgroup per CU, activations loaded once): 3 x 3, more than 64 input channels
+    static bool direct9_ok(int Cin, int W, int KT, int src_mode, bool plain) {
+        static const bool off = getenv("HICDIFF_WG_NO9") != nullptr;
+        return !off && KT == 3 && !src_mode && !plain && Cin > 64 && 2 * (W + 1) <= 192;
+    }
+    int run_direct9(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, float* dW, float* db, hipStream_t st, const float* affA = nullptr,
+                    const float* affB = nullptr, const float* affE = nullptr, float scale = 1.f, bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f) const {
+        static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
+        static const int want = getenv("HICDIFF_WG9_TARGET") ? atoi(getenv("HICDIFF_WG9_TARGET")) : 256;
+        const int Cin = C0 + C1, KT = 3;
+        const int Mt = (Cin + 127) / 128, Nt = Cout / 64, Mpad = Mt * 128;
+        const bool aff = affA || affB;
+        if (Cout % 64 || Cout > 1024 || C0 % 4 || C1 % 4 || !x0 || (C1 && !x1) || (aff && !affB)) { hd_set_error("wgrad (direct9): unsupported shape"); return -1; }
+        const long long Ktot = (long long)B * (H + 1) * (W + 1);
+        if (Ktot >= (1ll << 31) / (W + 2)) { hd_set_error("wgrad (direct9): too many pixels for the 32-bit position arithmetic"); return -1; }
+        const int total = (int)((Ktot + 63) / 64);
+        const size_t per_split_floats = (size_t)KT * KT * Mpad * Cout;
+        if (per_split_floats + 1024 > partial_floats) { hd_set_error("wgrad (direct9): the partial buffer is too small for this layer"); return -1; }
+        int sps = 0;
+        const int eff = pick_splits(Mt * Nt, total, per_split_floats, &sps, want);
+        const int nlead = (2 * (W + 1) + 63) / 64, R = nlead == 1 ? 128 : 256;
+        WgdArgs a{};
+        a.x0 = x0; a.x1 = x1; a.C0 = C0; a.C1 = C1; a.g = g; a.F = Cout; a.B = B; a.H = H; a.W = W;
+        a.magicW = (unsigned)((1ull << 32) / (unsigned)(W + 1)) + 1u; a.magicH = (unsigned)((1ull << 32) / (unsigned)(H + 1)) + 1u;
+        a.slices_per_split = sps; a.total_slices = total; a.nsplit = eff; a.Mtiles = Mt; a.Ntiles = Nt; a.M = Mpad;
+        a.partial = partial; a.biaspart = db ? partial + (size_t)eff * per_split_floats : nullptr; a.xcd_group = xcd_group;
+        a.affA = affA; a.affB = affB; a.affE = affE; a.aff_bs = aff_bs > 0 ? aff_bs : Cin; a.aff_addA = aff_addA; a.src_mode = 0;
+        const size_t lds = (size_t)R * 256 * 2 + (size_t)66 * 192 * 2;
+        hd_prof_begin("wgrad_direct9_kernel", 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
+        const dim3 grid(Mt * Nt * eff);
+#define HD_W9(AFF_)                                                                                                          \
+        do {                                                                                                                 \
+            static bool attr = false;                                                                                        \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_direct9_kernel<AFF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+            hipLaunchKernelGGL((wgrad_direct9_kernel<AFF_>), grid, dim3(512), lds, st, a, R);                                \
+        } while (0)
+        if (aff && affE) HD_W9(2); else if (aff) HD_W9(1); else HD_W9(0);
+#undef HD_W9
+        conv_prof_end(st);
+        if (check_launch("wgrad direct9")) return -3;
         const int nmain = (int)((per_split_floats + 255) / 256);
         hipLaunchKernelGGL(wg_reduce_kernel, dim3((unsigned)(nmain + (db ? (Cout + 255) / 256 : 0))), dim3(256), 0, st, partial, eff, Cin, Mpad, Cout, KT, scale,
                            accumulate ? 1 : 0, dW, a.biaspart, db, nmain);
