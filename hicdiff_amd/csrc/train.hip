@@ -314,7 +314,7 @@ __device__ __forceinline__ bf16x8 tr_read8(const char* p, int second) {      // 
 // slice on 8 x 8 maps) fetches its own at store time.  affA == null: A = 1; aff_addA is added to A (FiLM's scale + 1).
 // SRC: source addressing of X (WgdArgs::src_mode) -- compiled in, the position arithmetic sits in the loop.
 #ifdef HD_STAMPS
-__device__ unsigned long long g_wgd_stamps[1024][4];      // per workgroup (wave 0): cycles in the store phase (incl. the wait for the prefetched loads), in barriers, in the MFMA phase, total
+__device__ unsigned long long g_wgd_stamps[1024][5];      // per workgroup (wave 0): cycles in the store phase (incl. the wait for the prefetched loads), in barriers, in the MFMA phase, total
 #endif
 template <bool ONE, int TMW, int AFF = 0, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
@@ -706,12 +706,28 @@ __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
     }
     x_request(kbeg + Wp);
     g_request(kbeg);
+#ifdef HD_STAMPS
+    unsigned long long c_store = 0, c_bar = 0, c_req = 0, c_mma = 0, t0, t1;
+    const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < nslices; ++s) {
         const int k0 = kbeg + 64 * s;
+#ifdef HD_STAMPS
+        t0 = __builtin_readcyclecounter();
+#endif
         x_write(k0 + Wp);
         g_write();
+#ifdef HD_STAMPS
+        t1 = __builtin_readcyclecounter(); c_store += t1 - t0;
+#endif
         __syncthreads();
+#ifdef HD_STAMPS
+        t0 = __builtin_readcyclecounter(); c_bar += t0 - t1;
+#endif
         { const int sn = min(s + 1, nslices - 1); x_request(kbeg + 64 * sn + Wp); g_request(kbeg + 64 * sn); }
+#ifdef HD_STAMPS
+        t1 = __builtin_readcyclecounter(); c_req += t1 - t0;
+#endif
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 bh[3], bl[3];
@@ -733,8 +749,20 @@ __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
                 }
             }
         }
+#ifdef HD_STAMPS
+        t0 = __builtin_readcyclecounter(); c_mma += t0 - t1;
+#endif
         __syncthreads();
+#ifdef HD_STAMPS
+        c_bar += __builtin_readcyclecounter() - t0;
+#endif
     }
+#ifdef HD_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) {
+        g_wgd_stamps[blockIdx.x][0] = c_store; g_wgd_stamps[blockIdx.x][1] = c_bar; g_wgd_stamps[blockIdx.x][2] = c_mma;
+        g_wgd_stamps[blockIdx.x][3] = __builtin_readcyclecounter() - t_begin; g_wgd_stamps[blockIdx.x][4] = c_req;
+    }
+#endif
     const int N = 3 * a.F;
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
@@ -1714,7 +1742,7 @@ extern "C" int hd_debug_conv_wgrad_direct(const float* x0, int C0, const float* 
 
 #ifdef HD_STAMPS
 extern "C" int hd_debug_wgd_stamps(unsigned long long* out, int nwg) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgd_stamps), sizeof(unsigned long long) * 4 * nwg) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgd_stamps), sizeof(unsigned long long) * 5 * nwg) == hipSuccess ? 0 : -3;
 }
 #endif
 

@@ -47,12 +47,12 @@ def main():
     lib.hd_profile_enable(0)
     if hasattr(lib, "hd_debug_wgd_stamps"):
         import numpy as np
-        buf = (C.c_ulonglong * (4 * 1024))()
+        buf = (C.c_ulonglong * (5 * 1024))()
         if lib.hd_debug_wgd_stamps(buf, 1024) == 0:
-            s = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 4).astype(np.int64)
+            s = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 5).astype(np.int64)
             s = s[s[:, 3] > 0]
             print(f"  stamps over {len(s)} workgroups (cycles of wave 0, mean): store phase incl. wait for the prefetch {s[:, 0].mean():.0f}, barriers {s[:, 1].mean():.0f}, "
-                  f"request + MFMA phase {s[:, 2].mean():.0f}, total {s[:, 3].mean():.0f}")
+                  f"request + MFMA phase {s[:, 2].mean():.0f} (nine-tap kernel: MFMA phase alone; its request phase {s[:, 4].mean():.0f}), total {s[:, 3].mean():.0f}")
 
 
 if __name__ == "__main__":
