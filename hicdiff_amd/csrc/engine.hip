@@ -176,6 +176,21 @@ struct Loader {
             c->owned.push_back(p);
             w->wsplit = (unsigned short*)p;
         }
+        {   // 3x3 layers with at most 64 output channels also get an image with 16-channel slices: on maps of >= 4096 pixels their 256 x 64 tile
+            // then needs ~40 KB of LDS and (registers capped at 168, conv_bf16x3_kernel.h) a third workgroup fits a CU -- 271 -> 258 us on the
+            // dominant unet64 kernel, 13.93 -> 13.77 ms per step on one box; smaller maps keep 32 (unet40: 3.07 vs 3.09 ms).  pick_slices()
+            // chooses per launch, by the map size only.  HICDIFF_CK16_NARROW=0 turns the second image off.
+            static const bool ck16n = !(getenv("HICDIFF_CK16_NARROW") && atoi(getenv("HICDIFF_CK16_NARROW")) == 0);
+            if (ck16n && KH == 3 && !unshuffle && w->CoutPad == 64 && w->ck == 32) {
+                if (!w->wsplit16) {
+                    void* p = nullptr;
+                    if (hipMalloc(&p, (size_t)KH * KH * cin * w->CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
+                    c->owned.push_back(p);
+                    w->wsplit16 = (unsigned short*)p;
+                }
+                HD_TRY(launch_split_conv(w->w, w->wsplit16, KH * KH, cin, w->CoutPad, 16, st));
+            }
+        }
         HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, w->ck, st));
         if (KH == 3 && !unshuffle && cin % 16 == 0 && cout % 4 == 0) {      // Winograd image of the 3x3 filters (conv_winograd.hip)
             if (!w->wino) {
@@ -373,7 +388,14 @@ static int probe(Run& r, const std::string& label, const Act& a) {
     return 0;
 }
 
+// the 16-channel-slice image of a layer that has one, on large maps (a rule by the layer and the map size only)
+static void pick_slices(ConvArgs& a) {
+    if (a.cw.wsplit16 && a.H * a.W >= 4096) { a.cw.wsplit = a.cw.wsplit16; a.cw.ck = 16; }
+    a.cw.wsplit16 = nullptr;
+}
+
 static int run_conv(Run& r, ConvArgs& a) {
+    pick_slices(a);
     a.precision = r.c->precision;
     // the dry run sizes the workspace for either arithmetic (hd_set_precision may switch later): plan the split as the fast path would
     ConvArgs probe = a; probe.precision = HD_PREC_BF16X3;
@@ -391,6 +413,7 @@ static int run_conv(Run& r, ConvArgs& a) {
 static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* beta, int film_mode, int film_off,
                    float** A, float** Bv, float** E) {
     const int HW = a.H * a.W;
+    pick_slices(a);
     a.precision = r.c->precision;
     int slots = conv_gn_slots(a);
     const bool fused = slots > 0;

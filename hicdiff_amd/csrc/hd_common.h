@@ -18,6 +18,7 @@ struct Act {
 struct ConvW {
     float* w = nullptr;
     unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/ck][CoutPad][ck hi | ck lo] (fast path)
+    unsigned short* wsplit16 = nullptr; // optional second split image with 16-channel slices, taken on feature maps of >= 4096 pixels (engine.hip pick_slices)
     unsigned short* wino = nullptr;     // 3x3 only: Winograd F(2x2,3x3) filter transform, split bf16, MFMA-fragment order (conv_winograd.hip)
     float* bias = nullptr;
     int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;
