@@ -393,6 +393,10 @@ def test_weight_gradient_component_any_shape(B, S, C0, C1, Cout, KT, aff, plain)
     (3, 5, 128, 0, 128, 3, 1),         # normalised-activation input; three samples inside one 64-position slice
     (2, 64, 64, 0, 64, 3, 1),
     (2, 16, 256, 0, 256, 3, 2),        # + SR3's additive embedding after the SiLU
+    (1, 31, 128, 0, 64, 3, 0),         # nine-tap kernel: 64 + 2 (W + 1) = 128 positions, the 128-slot ring exactly full
+    (2, 32, 192, 0, 64, 3, 0),         # one more column: the 256-slot ring; 192 input channels = a padded second row tile
+    (1, 33, 128, 64, 384, 3, 1),       # odd width, concat + affine input, six column tiles
+    (1, 64, 128, 0, 64, 3, 1),         # 194 of the ring's 256 slots in use (the hicedrn shape at one sample)
 ])
 def test_weight_gradient_direct_from_nhwc(B, S, C0, C1, Cout, KT, aff):
     """wgrad_direct_kernel (operands read as the forward left them, transposed LDS reads) against torch's conv2d weight gradient and
