@@ -147,7 +147,8 @@ int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float*
                        const float* film, int film_bs, int film_off, int film_mode, int B, int HW, int C, int G, float* scratch, float* dgamma, float* dbeta,
                        float* dfilm, int accumulate, hipStream_t st, int dfilm_bs = 0);
 size_t ln_bwd_scratch_floats(size_t P, int C);
-int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st);
+int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st,
+                  const float* add = nullptr);   // add (may be dout): dout = add + dx
 int launch_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* dw, hipStream_t st);
 int launch_ws_fwd(const float* w, int Cout, int n, float* out, hipStream_t st);
 int launch_attn_full_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, hipStream_t st);   // train_attn.hip

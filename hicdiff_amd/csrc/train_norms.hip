@@ -187,9 +187,10 @@ __global__ __launch_bounds__(256) void gn_param_grads_kernel(const float* __rest
 // once (four at C = 64; round 1's one-row-per-wave, one-channel-per-lane form ran at a third of the memory rate there).  Each lane
 // keeps its channels' d gain sums in registers; lanes, waves and then workgroups (part[blockIdx][C], col_sum afterwards) are combined
 // in a fixed order.  NV = float4s per lane.
+// add (optional, may be dout): dout = add + dx -- the gradient accumulates into a tensor that already holds other contributions.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* dy, float* dout, const float* __restrict__ gain, size_t P, int C,
-                                                     int rows_per_block, float* __restrict__ part) {
+                                                     int rows_per_block, float* __restrict__ part, const float* add) {
     extern __shared__ float dg[];                           // [4 waves][64 / LPR rows][C]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int lpr = C / (4 * NV), rpw = 64 / lpr;          // lanes per row, rows per wave
@@ -234,8 +235,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
         if (live) {
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const float4 o = make_float4(rs * (dv[v].x - s1 - xv[v].x * s2), rs * (dv[v].y - s1 - xv[v].y * s2), rs * (dv[v].z - s1 - xv[v].z * s2),
-                                             rs * (dv[v].w - s1 - xv[v].w * s2));
+                float4 o = make_float4(rs * (dv[v].x - s1 - xv[v].x * s2), rs * (dv[v].y - s1 - xv[v].y * s2), rs * (dv[v].z - s1 - xv[v].z * s2),
+                                       rs * (dv[v].w - s1 - xv[v].w * s2));
+                if (add) { const float4 t = *reinterpret_cast<const float4*>(add + r * C + (sub + v * lpr) * 4); o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; }
                 *reinterpret_cast<float4*>(dout + r * C + (sub + v * lpr) * 4) = o;
             }
         }
@@ -334,15 +336,16 @@ int launch_gn_silu_bwd(const float* x, const float* g, float* gout, const float*
 // scratch: one d-gain row per workgroup of 256 pixel rows, and 32 rows for the first level of their sum
 size_t ln_bwd_scratch_floats(size_t P, int C) { return ((P + 255) / 256 + 32) * (size_t)C; }
 
-int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st) {
+int launch_ln_bwd(const float* x, const float* dy, float* dout, const float* gain, size_t P, int C, float* scratch, float* dgain, int accumulate, hipStream_t st,
+                  const float* add) {
     if (C % 64 || C > 512 || (C > 256 && C != 512)) { hd_set_error("ln backward: channels must be 64, 128, 192, 256 or 512"); return -1; }
     const int rows = 256;
     const unsigned nb = (unsigned)((P + rows - 1) / rows);
     const int nv = C == 512 ? 2 : 1, lpr = C / (4 * nv);
     if (64 % lpr) { hd_set_error("ln backward: unsupported channel count"); return -1; }
     const size_t lds = (size_t)4 * (64 / lpr) * C * sizeof(float);
-    if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch);
-    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch);
+    if (nv == 2) hipLaunchKernelGGL(ln_bwd_kernel<2>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch, add);
+    else hipLaunchKernelGGL(ln_bwd_kernel<1>, dim3(nb), dim3(256), lds, st, x, dy, dout, gain, P, C, rows, scratch, add);
     // sum over the workgroups' rows: two levels when there are many (one thread per column walking thousands of rows was 47 us)
     if (nb >= 256) {
         float* lvl = scratch + (size_t)nb * C;
