@@ -214,25 +214,34 @@ int conv_splitk(const ConvArgs& a) {
 // path have at most 128 pixels; Cout is a multiple of 64.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t per_split, const float* __restrict__ bias, int HW,
                                                             int Cout, float* __restrict__ out, float* __restrict__ gn_part) {
-    // workgroup = (sample, 64 channels); thread = (channel, one of four pixel groups): 256-byte rows, four pixels in flight per channel
-    __shared__ float r1[4][64], r2[4][64];
-    const int b = blockIdx.y, cl = threadIdx.x & 63, pg = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
-    const float bv = bias ? bias[c] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = pg; p < HW; p += 4) {
+    // workgroup = (sample, 64 channels); thread = (channel quad, one of sixteen pixel groups): float4 accesses, at most eight pixels per
+    // thread on the 10 x 10 maps (one channel and every fourth pixel per thread ran 25 dependent rounds: 12 us per launch, 17 launches)
+    __shared__ float r1[16][64], r2[16][64];
+    const int b = blockIdx.y, cq = threadIdx.x & 15, pg = threadIdx.x >> 4, c = blockIdx.x * 64 + cq * 4;
+    const float4 bv = bias ? *reinterpret_cast<const float4*>(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    for (int p = pg; p < HW; p += 16) {
         const size_t e = ((size_t)b * HW + p) * Cout + c;
-        float v = ws[e];
-        for (int k = 1; k < nsplit; ++k) v += ws[(size_t)k * per_split + e];
-        v += bv;
-        out[e] = v;
-        s1 += v; s2 += v * v;
+        float4 v = *reinterpret_cast<const float4*>(ws + e);
+        for (int k = 1; k < nsplit; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(ws + (size_t)k * per_split + e);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        *reinterpret_cast<float4*>(out + e) = v;
+        s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
+        s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
     }
     if (!gn_part) return;
-    r1[pg][cl] = s1; r2[pg][cl] = s2;
+    *reinterpret_cast<float4*>(&r1[pg][cq * 4]) = s1;
+    *reinterpret_cast<float4*>(&r2[pg][cq * 4]) = s2;
     __syncthreads();
-    if (pg == 0)
-        *reinterpret_cast<float2*>(gn_part + ((size_t)b * Cout + c) * 2) =
-            make_float2((r1[0][cl] + r1[1][cl]) + (r1[2][cl] + r1[3][cl]), (r2[0][cl] + r2[1][cl]) + (r2[2][cl] + r2[3][cl]));
+    if (threadIdx.x < 64) {
+        const int cl = threadIdx.x;
+        float a = 0.f, q = 0.f;
+        for (int g = 0; g < 16; ++g) { a += r1[g][cl]; q += r2[g][cl]; }
+        *reinterpret_cast<float2*>(gn_part + ((size_t)b * Cout + blockIdx.x * 64 + cl) * 2) = make_float2(a, q);
+    }
 }
 
 int conv_gn_slots(const ConvArgs& a) {
