@@ -150,12 +150,25 @@ __global__ __launch_bounds__(256) void linattn_bwd_combine_kernel(const float* _
     float rpart[4];
     for (int j = 0; j < 4; ++j) {                            // element i = tid + 256 j = (d, e); d = i / 32 is the same for 32 consecutive i
         const int i = tid + 256 * j, d = i / D;
-        float c = 0.f, dc = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const float* q = p + (size_t)ch * LA_PART;
-            c += q[64 + i] * __expf(q[d] - M[d]);
-            dc += q[64 + 1024 + i];
+        // four chunks per round with their own accumulators: the loads of a round are independent, so they travel together (one chunk
+        // at a time this loop was a chain of 64 dependent round trips on the 64 x 64 maps: 150 us)
+        float c4[4] = {0.f, 0.f, 0.f, 0.f}, d4[4] = {0.f, 0.f, 0.f, 0.f};
+        int ch = 0;
+        for (; ch + 4 <= nchunk; ch += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* q = p + (size_t)(ch + u) * LA_PART;
+                c4[u] += q[64 + i] * __expf(q[d] - M[d]);
+                d4[u] += q[64 + 1024 + i];
+            }
         }
+        for (; ch < nchunk; ++ch) {
+            const float* q = p + (size_t)ch * LA_PART;
+            c4[0] += q[64 + i] * __expf(q[d] - M[d]);
+            d4[0] += q[64 + 1024 + i];
+        }
+        float c = (c4[0] + c4[1]) + (c4[2] + c4[3]);
+        const float dc = (d4[0] + d4[1]) + (d4[2] + d4[3]);
         c /= S[d];
         out[96 + i] = c; out[96 + 1024 + i] = dc;
         rpart[j] = c * dc;
