@@ -488,7 +488,8 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 // (16-channel slices with the 256 x 64 tile: ~40 KB of LDS, so a third workgroup fits a CU if the registers allow -- at most 168.  The same cap on
 // the 128 x 128 variants with 16-channel slices everywhere measured a loss: 14.1 vs 13.45 ms per unet64 step.)
-__global__ __launch_bounds__(64 * WM * WN, (CK == 16 && WM == 4 && WN == 1) ? 3 : 1) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+// Only the plain loader fits 168 registers without scratch (the GroupNorm-apply loaders need 196: capped, they spill 12 registers -- tests/test_isa_guards.py).
+__global__ __launch_bounds__(64 * WM * WN, (CK == 16 && WM == 4 && WN == 1 && MODE == IN_NONE) ? 3 : 1) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, false>(p);
 }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>

@@ -178,8 +178,8 @@ struct Loader {
         }
         {   // 3x3 layers with at most 64 output channels also get an image with 16-channel slices: on maps of >= 4096 pixels their 256 x 64 tile
             // then needs ~40 KB of LDS and (registers capped at 168, conv_bf16x3_kernel.h) a third workgroup fits a CU -- 271 -> 258 us on the
-            // dominant unet64 kernel, 13.93 -> 13.77 ms per step on one box; smaller maps keep 32 (unet40: 3.07 vs 3.09 ms).  pick_slices()
-            // chooses per launch, by the map size only.  HICDIFF_CK16_NARROW=0 turns the second image off.
+            // dominant unet64 kernel; with the plain-loader layers only (the others would spill) 13.59 -> 13.50 ms per step on one box; smaller
+            // maps keep 32 (unet40: 3.07 vs 3.09 ms).  pick_slices() chooses per launch, by the loader and the map size only.  HICDIFF_CK16_NARROW=0 turns the second image off.
             static const bool ck16n = !(getenv("HICDIFF_CK16_NARROW") && atoi(getenv("HICDIFF_CK16_NARROW")) == 0);
             if (ck16n && KH == 3 && !unshuffle && w->CoutPad == 64 && w->ck == 32) {   // (the 1x1 shortcuts of those layers: no change, 13.43 vs 13.42 ms)
                 if (!w->wsplit16) {
@@ -388,9 +388,9 @@ static int probe(Run& r, const std::string& label, const Act& a) {
     return 0;
 }
 
-// the 16-channel-slice image of a layer that has one, on large maps (a rule by the layer and the map size only)
+// the 16-channel-slice image of a layer that has one, on large maps with the plain loader (a rule by the layer, its loader and the map size only)
 static void pick_slices(ConvArgs& a) {
-    if (a.cw.wsplit16 && a.H * a.W >= 4096) { a.cw.wsplit = a.cw.wsplit16; a.cw.ck = 16; }
+    if (a.cw.wsplit16 && a.H * a.W >= 4096 && a.in_mode == IN_NONE) { a.cw.wsplit = a.cw.wsplit16; a.cw.ck = 16; }   // (the transforming loaders need more registers than three workgroups per CU leave)
     a.cw.wsplit16 = nullptr;
 }
 
