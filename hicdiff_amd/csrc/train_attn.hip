@@ -99,7 +99,11 @@ __device__ __forceinline__ void la_softmax_d(float (&q)[D]) {
 
 __global__ __launch_bounds__(64) void linattn_bwd_partial_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, int n, int heads, int nchunk,
                                                                  float* __restrict__ part) {
-    __shared__ float kk[LA_TOK][D + 1], vv[LA_TOK][D + 1], qq[LA_TOK][D + 1], dd[LA_TOK][D + 1], mm[D];
+    // rows of 36 floats: 16-byte aligned, so a token's row is written and a 4-channel group read as float4 (one b32 access per operand
+    // made the pair loop LDS-issue bound: two reads per FMA)
+    constexpr int LP = D + 4;
+    __shared__ __attribute__((aligned(16))) float kk[LA_TOK][LP], vv[LA_TOK][LP], qq[LA_TOK][LP], dd[LA_TOK][LP];
+    __shared__ float mm[D];
     const int ck = blockIdx.x % nchunk, bh = blockIdx.x / nchunk, b = bh / heads, h = bh % heads, lane = threadIdx.x;
     const int C3 = 3 * heads * D, C1 = heads * D, tok = ck * LA_TOK + lane;
     const bool on = tok < n;
@@ -112,9 +116,11 @@ __global__ __launch_bounds__(64) void linattn_bwd_partial_kernel(const float* __
     }
     const float invn = 1.f / (float)n;
 #pragma unroll
-    for (int j = 0; j < D; ++j) {
-        kk[lane][j] = on ? k[j] : -3.0e38f; vv[lane][j] = on ? v[j] * invn : 0.f;
-        qq[lane][j] = on ? q[j] * SCALE : 0.f; dd[lane][j] = on ? g[j] : 0.f;
+    for (int j = 0; j < D; j += 4) {
+        *reinterpret_cast<float4*>(&kk[lane][j]) = on ? make_float4(k[j], k[j + 1], k[j + 2], k[j + 3]) : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+        *reinterpret_cast<float4*>(&vv[lane][j]) = on ? make_float4(v[j] * invn, v[j + 1] * invn, v[j + 2] * invn, v[j + 3] * invn) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&qq[lane][j]) = on ? make_float4(q[j] * SCALE, q[j + 1] * SCALE, q[j + 2] * SCALE, q[j + 3] * SCALE) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&dd[lane][j]) = on ? make_float4(g[j], g[j + 1], g[j + 2], g[j + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     float* out = part + (size_t)blockIdx.x * LA_PART;
@@ -126,11 +132,26 @@ __global__ __launch_bounds__(64) void linattn_bwd_partial_kernel(const float* __
         mm[lane] = mx; out[lane] = mx; out[D + lane] = s;
     }
     __syncthreads();
-    for (int i = lane; i < D * D; i += 64) {                // (d, e) pairs
-        const int d = i / D, e = i % D;
-        float c = 0.f, dc = 0.f;
-        for (int t = 0; t < LA_TOK; ++t) { c += kk[t][d] * vv[t][e]; dc += qq[t][d] * dd[t][e]; }
-        out[64 + i] = c; out[64 + 1024 + i] = dc;
+    // lane = a 4 x 4 block of (d, e) pairs: four float4 reads per token feed 32 FMAs; each pair still adds its tokens in order
+    const int d0 = (lane >> 3) * 4, e0 = (lane & 7) * 4;
+    float c[4][4], dc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b2 = 0; b2 < 4; ++b2) { c[a][b2] = 0.f; dc[a][b2] = 0.f; }
+    for (int t = 0; t < LA_TOK; ++t) {
+        const float4 k4 = *reinterpret_cast<const float4*>(&kk[t][d0]), v4 = *reinterpret_cast<const float4*>(&vv[t][e0]);
+        const float4 q4 = *reinterpret_cast<const float4*>(&qq[t][d0]), g4 = *reinterpret_cast<const float4*>(&dd[t][e0]);
+        const float ka[4] = {k4.x, k4.y, k4.z, k4.w}, va[4] = {v4.x, v4.y, v4.z, v4.w}, qa[4] = {q4.x, q4.y, q4.z, q4.w}, ga[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b2 = 0; b2 < 4; ++b2) { c[a][b2] += ka[a] * va[b2]; dc[a][b2] += qa[a] * ga[b2]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        *reinterpret_cast<float4*>(out + 64 + (d0 + a) * D + e0) = make_float4(c[a][0], c[a][1], c[a][2], c[a][3]);
+        *reinterpret_cast<float4*>(out + 64 + 1024 + (d0 + a) * D + e0) = make_float4(dc[a][0], dc[a][1], dc[a][2], dc[a][3]);
     }
 }
 
@@ -184,7 +205,10 @@ __global__ __launch_bounds__(256) void linattn_bwd_combine_kernel(const float* _
 
 __global__ __launch_bounds__(64) void linattn_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ fin, int n,
                                                                int heads, int nchunk, float* __restrict__ dqkv) {
-    __shared__ float ctx[D][D + 1], dctx[D][D + 1], M[D], S[D], R[D];
+    // rows of 32 floats, 16-byte aligned: every lane reads the same address (a broadcast: no conflicts at any pitch), and the unrolled loops'
+    // constant offsets then merge into ds_read_b128
+    __shared__ __attribute__((aligned(16))) float ctx[D][D], dctx[D][D];
+    __shared__ float M[D], S[D], R[D];
     const int ck = blockIdx.x % nchunk, bh = blockIdx.x / nchunk, b = bh / heads, h = bh % heads, lane = threadIdx.x;
     const float* f = fin + (size_t)bh * LA_FIN;
     for (int i = lane; i < D * D; i += 64) { ctx[i / D][i % D] = f[96 + i]; dctx[i / D][i % D] = f[96 + 1024 + i]; }
