@@ -429,12 +429,13 @@ __global__ __launch_bounds__(256) void linattn_context_kernel(const float* __res
         for (int i = tid; i < CH * D; i += 256) {
             int r = i / D, c = i % D;
             float kv = 0.f, vv = 0.f;
-            if (r < cnt) { kv = base[(size_t)(n0 + r) * C3 + koff + c]; vv = base[(size_t)(n0 + r) * C3 + voff + c]; }
+            // the exponential is taken once per (token, d) here, not once per (token, d, e-quad) in the loop below (eight threads share a d)
+            if (r < cnt) { kv = __expf(base[(size_t)(n0 + r) * C3 + koff + c] - kmax[c]); vv = base[(size_t)(n0 + r) * C3 + voff + c]; }
             ks[r][c] = kv; vs[r][c] = vv;
         }
         __syncthreads();
         for (int r = 0; r < cnt; ++r) {
-            const float pexp = __expf(ks[r][dd] - m_d);
+            const float pexp = ks[r][dd];
             const float4 vv = *reinterpret_cast<const float4*>(&vs[r][e0]);
             ps += pexp;
             acc0 += pexp * vv.x; acc1 += pexp * vv.y; acc2 += pexp * vv.z; acc3 += pexp * vv.w;
