@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256) void linattn_bwd_combine_kernel(const float* _
     }
 }
 
+// (Register caps were tried: 168 / 128 registers per wave spill 144 / 304 of them and the kernel goes 127 -> 176 / 305 us; uncapped it uses ~290.)
 __global__ __launch_bounds__(64) void linattn_bwd_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ dout, const float* __restrict__ fin, int n,
                                                                int heads, int nchunk, float* __restrict__ dqkv) {
     // rows of 32 floats, 16-byte aligned: every lane reads the same address (a broadcast: no conflicts at any pitch), and the unrolled loops'
@@ -217,28 +218,36 @@ __global__ __launch_bounds__(64) void linattn_bwd_apply_kernel(const float* __re
     const int C3 = 3 * heads * D, C1 = heads * D, tok = ck * LA_TOK + lane;
     if (tok >= n) return;
     const float* row = qkv + ((size_t)b * n + tok) * C3 + h * D;
-    float q[D], k[D], v[D], g[D];
-    la_load_row(row, q); la_load_row(row + C1, k); la_load_row(row + 2 * C1, v);
-    la_load_row(dout + ((size_t)b * n + tok) * C1 + h * D, g);
-    la_softmax_d(q);
+    // two phases with disjoint register sets (q, dout, t -> dq; then k, v, dv -> dk, dv)
     const float invn = 1.f / (float)n;
-    float t[D], dot = 0.f;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {                            // d q'[d] = sum_e context[d][e] dout[e]; times scale
-        float s = 0.f;
-#pragma unroll
-        for (int e = 0; e < D; ++e) s += ctx[d][e] * g[e];
-        t[d] = s * SCALE; dot += q[d] * t[d];
-    }
     float* drow = dqkv + ((size_t)b * n + tok) * C3 + h * D;
+    {
+        float q[D], g[D];
+        la_load_row(row, q);
+        la_load_row(dout + ((size_t)b * n + tok) * C1 + h * D, g);
+        la_softmax_d(q);
+        float t[D], dot = 0.f;
 #pragma unroll
-    for (int d = 0; d < D; d += 4)
-        *reinterpret_cast<float4*>(drow + d) = make_float4(q[d] * (t[d] - dot), q[d + 1] * (t[d + 1] - dot), q[d + 2] * (t[d + 2] - dot), q[d + 3] * (t[d + 3] - dot));
+        for (int d = 0; d < D; ++d) {                        // d q'[d] = sum_e context[d][e] dout[e]; times scale
+            __builtin_amdgcn_sched_barrier(0);               // keep each row's LDS reads inside its iteration
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < D; ++e) s += ctx[d][e] * g[e];
+            t[d] = s * SCALE; dot += q[d] * t[d];
+        }
+#pragma unroll
+        for (int d = 0; d < D; d += 4)
+            *reinterpret_cast<float4*>(drow + d) = make_float4(q[d] * (t[d] - dot), q[d + 1] * (t[d + 1] - dot), q[d + 2] * (t[d + 2] - dot), q[d + 3] * (t[d + 3] - dot));
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // the second phase's rows are requested after the first phase has retired its registers
+    float k[D], v[D];
+    la_load_row(row + C1, k); la_load_row(row + 2 * C1, v);
     float kp[D], dv[D];
 #pragma unroll
     for (int e = 0; e < D; ++e) dv[e] = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
+        __builtin_amdgcn_sched_barrier(0);
         kp[d] = __expf(k[d] - M[d]) / S[d];
         float s = 0.f;
 #pragma unroll
