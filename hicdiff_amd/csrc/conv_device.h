@@ -263,6 +263,38 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     pixs[pass] = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
                     rows[pass] = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                 }
+#if defined(HD_EPI_V9)       /* REPRO of the asymmetry in DESIGN.md section 8 (make EXTRA=-DHD_EPI_V9): a uniform branch on `two` AND selects in the two-image branch.
+                                Either change alone (selects in the single loop; the branch with exec-masked regions) is bit-consistent. */
+                if (!two) {
+#pragma unroll
+                    for (int pass = 0; pass < NPASS; ++pass) {
+                        const int pix = pixs[pass];
+                        const float4 a4 = rows[pass];
+                        const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                        if (pix >= 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { const float x = o4[j]; s1[0][j] += x; s2[0][j] += x * x; }
+                            if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int pass = 0; pass < NPASS; ++pass) {
+                        const int lr = pass * RPP + rg;
+                        const int pix = pixs[pass];
+                        const bool up = lr >= 32;
+                        const float4 a4 = rows[pass];
+                        const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
+                        const bool live = pix >= 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = live ? o4[j] : 0.f, lo = up ? 0.f : x, hi = up ? x : 0.f;
+                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
+                        }
+                        if (live && !(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                    }
+                }
+#else
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     const int lr = pass * RPP + rg;
@@ -279,6 +311,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                         if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
                     }
                 }
+#endif
             } else if (vec) {
                 // General path: the residual / FiLM operands of pass i+1 are requested BEFORE pass i is stored, so the
                 // wait for them (vmcnt(1)) never includes the store that was issued after them.
