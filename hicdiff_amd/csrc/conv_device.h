@@ -252,9 +252,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 // All passes' LDS reads (row -> pixel table, staged row) are issued first: read one pass at a time, behind
                 // the previous pass's guarded store, every pass paid two exposed LDS round trips (HD_STAMPS: 640 cycles per pass, 10 k of a
                 // 14 k-cycle epilogue on the 64-channel layers; skipping the stores altogether changed nothing).
-                // (A further split of this loop into a one-sample form without the upper / lower-half selects measured another -1.1 % per
-                // step but made an 8x8 map's result depend on which half of the tile the sample sits in -- tile results must not depend on
-                // the batch, tests/test_gpu_parity.py::test_batch_independence_and_determinism_full_size -- and was dropped.)
+                // Instruction count matters here more than anywhere else in the kernel: this wave shares its SIMD with a wave of the CU's
+                // other workgroup that is in its MFMA loop, and each VALU instruction waits for an issue slot between that wave's MFMAs.
                 int pixs[NPASS];
                 float4 rows[NPASS];
 #pragma unroll
@@ -263,19 +262,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     pixs[pass] = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
                     rows[pass] = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                 }
-#if defined(HD_EPI_V9)       /* REPRO of the asymmetry in DESIGN.md section 8 (make EXTRA=-DHD_EPI_V9): a uniform branch on `two` AND selects in the two-image branch.
-                                Either change alone (selects in the single loop; the branch with exec-masked regions) is bit-consistent. */
+                // One sample per tile (all but the 8x8 maps): one set of sums, no upper / lower-half selects.  The squares are accumulated with an
+                // EXPLICIT fma in both branches: under -ffp-contract=fast hipcc fuses `s += x * x` in some instances of this loop and not
+                // in others (tools/epilogue_sum_repro.hip: 4 % of the sums differ in the last bit between two equivalent forms, and between the
+                // two halves of a two-image tile), and a tile's result must not depend on where the sample sits or on the batch.
+                float* const obase = p.out + n;
+                const bool keep = !(p.ablate & 1);
                 if (!two) {
 #pragma unroll
                     for (int pass = 0; pass < NPASS; ++pass) {
                         const int pix = pixs[pass];
                         const float4 a4 = rows[pass];
+                        const bool live = pix >= 0;
                         const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
-                        if (pix >= 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { const float x = o4[j]; s1[0][j] += x; s2[0][j] += x * x; }
-                            if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
-                        }
+                        for (int j = 0; j < 4; ++j) { const float x = live ? o4[j] : 0.f; s1[0][j] += x; s2[0][j] = __builtin_fmaf(x, x, s2[0][j]); }
+                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)(pix * p.Cout)) = o4;
                     }
                 } else {
 #pragma unroll
@@ -287,31 +289,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                         const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
                         const bool live = pix >= 0;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
+                        for (int j = 0; j < 4; ++j) {   // selects, not indexing: a dynamically indexed register array goes to scratch
                             const float x = live ? o4[j] : 0.f, lo = up ? 0.f : x, hi = up ? x : 0.f;
-                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
+                            s1[0][j] += lo; s2[0][j] = __builtin_fmaf(lo, lo, s2[0][j]); s1[1][j] += hi; s2[1][j] = __builtin_fmaf(hi, hi, s2[1][j]);
                         }
-                        if (live && !(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
+                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)(pix * p.Cout)) = o4;
                     }
                 }
-#else
-#pragma unroll
-                for (int pass = 0; pass < NPASS; ++pass) {
-                    const int lr = pass * RPP + rg;
-                    const int pix = pixs[pass];
-                    const bool up = two && lr >= 32;
-                    const float4 a4 = rows[pass];
-                    const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
-                    if (pix >= 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float x = o4[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
-                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
-                        }
-                        if (!(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
-                    }
-                }
-#endif
             } else if (vec) {
                 // General path: the residual / FiLM operands of pass i+1 are requested BEFORE pass i is stored, so the
                 // wait for them (vmcnt(1)) never includes the store that was issued after them.
@@ -364,7 +348,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = v[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
-                            s1[0][j] += lo; s2[0][j] += lo * lo; s1[1][j] += hi; s2[1][j] += hi * hi;
+                            s1[0][j] += lo; s2[0][j] = __builtin_fmaf(lo, lo, s2[0][j]); s1[1][j] += hi; s2[1][j] = __builtin_fmaf(hi, hi, s2[1][j]);   // explicit fma: see the fast path
                         }
                     }
                     if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {

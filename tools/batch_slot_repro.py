@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Repro driver for the two-image-tile asymmetry of DESIGN.md section 8 (GPU box):
-    cd hicdiff_amd/csrc && rm -f conv_bf16x3_ck32.o conv_bf16x3_ck16.o && make EXTRA=-DHD_EPI_V9 && cd ../.. && python3 tools/batch_slot_repro.py
-With the product build every figure printed is 0; with HD_EPI_V9 the samples whose 8x8 maps sit in the LOWER half of a two-image tile differ
-from the same samples computed alone (4e-5), the upper-half ones do not."""
+"""Checks that a tile's result does not depend on its position in a two-image workgroup tile (a loop form whose
+`s += x * x` hipcc contracted in some instances and not in others made the lower-half samples of the 8x8 maps differ by 4e-5 from the same
+samples computed alone).  Every figure printed must be 0.  The reduced form of the effect: tools/epilogue_sum_repro.hip."""
 import os
 import sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
