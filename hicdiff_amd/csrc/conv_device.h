@@ -344,7 +344,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     if (pass + 1 < NPASS) fetch(pass + 1);
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
-                    if (pix >= 0) {
+                    if (p.gn_part && pix >= 0) {          // (no GroupNorm follows the shortcut / projection convolutions that take this path: skip the sums)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = v[j], lo = up ? 0.f : x, hi = up ? x : 0.f;
