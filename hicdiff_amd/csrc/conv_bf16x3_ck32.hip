@@ -45,7 +45,7 @@ int launch_conv_bf16x3_ck32(ConvLaunch& L, hipStream_t st) {
 #ifdef HD_STAMPS
 extern "C" int hd_debug_conv_stamps(unsigned long long* out, int nwg) {
     if (nwg < 1 || nwg > 4096) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 6 * nwg) == hipSuccess ? 0 : -3;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 12 * nwg) == hipSuccess ? 0 : -3;
 }
 extern "C" int hd_debug_conv_epi_stamps(unsigned long long* out, int nwg) {
     if (nwg < 1 || nwg > 4096) return -1;

@@ -45,7 +45,7 @@
 // make EXTRA=-DHD_STAMPS: wave 0 of every workgroup below 4096 leaves cycle stamps (start, loop entry, loop exit, end, cycles spent in the
 // loop's barriers, XCC / CU id) in a device array that tools/conv_probe.py prints -- a timing study, never part of the product build.
 #ifdef HD_STAMPS
-static __device__ unsigned long long g_conv_stamps[4096][6];
+static __device__ unsigned long long g_conv_stamps[4096][12];   // [6]: cycles from kernel entry to the first window's loads being issued; [7]: from there until they have arrived (s_waitcnt vmcnt(0))
 #define HD_STAMP() __builtin_readcyclecounter()
 #endif
 
@@ -137,7 +137,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 
 #ifdef HD_STAMPS
     const unsigned long long st_begin = HD_STAMP();
-    unsigned long long st_bar = 0;
+    unsigned long long st_bar = 0, st_issue = 0, st_arrive = 0, st_a = 0, st_b = 0, st_c = 0, st_d = 0;
 #endif
     const TileCtx t = tile_decode<WN, BN>(p);
     const int tid = t.tid;
@@ -184,9 +184,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
             if constexpr (NV > 2) *reinterpret_cast<float4*>(d + 2 * ptv) = pr2;
         }
     };
+#ifdef HD_STAMPS
+    st_a = HD_STAMP();                 // tile decoded
+#endif
     pt_load(0);
     init_tables<BM, NT>(p, t, pxsrc, pxb, rowpix, rowb);
     pt_store(0);
+#ifdef HD_STAMPS
+    st_b = HD_STAMP();                 // tables written
+#endif
 
     int aoff[TM], boff[TN];
 #pragma unroll
@@ -205,6 +211,9 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     const int ntaps = NTAPS ? NTAPS : p.KH * p.KW, nchunks_tot = p.Cin / CK;
     const int nchunks = (NTAPS == 9 && p.ksplit > 1) ? min(p.kchunks, nchunks_tot - cb) : nchunks_tot, nit = ntaps * nchunks;
     __syncthreads();                 // tables and the parameter table of slice 0 visible
+#ifdef HD_STAMPS
+    st_c = HD_STAMP();                 // first barrier passed
+#endif
 
     // per-thread staging items: item i = tid + NT*j = (pixel i / IPP, channels 8*(i % IPP)..+7).  NT is a
     // multiple of IPP, so the channel offset q8 is the same for all of a thread's items and its pixels are
@@ -343,6 +352,9 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int IPT = (MAXI + 6) / 7;
     constexpr int XLAT = 3;
 
+#ifdef HD_STAMPS
+    st_d = HD_STAMP();                 // per-thread items set up
+#endif
     // ---- prologue: slice 0 and weight slab 0 staged, slab 1 in flight
     {
         const float* src; int Csrc;
@@ -350,6 +362,11 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
         w_load(S0{}, 0, 0);
+#ifdef HD_STAMPS
+        st_issue = HD_STAMP();
+        __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0) (gfx9 encoding: lgkmcnt / expcnt untouched): how long do the first loads take to arrive?
+        st_arrive = HD_STAMP();
+#endif
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_stage(j, 0, Xs);
         w_store(S0{}, 0);
@@ -480,7 +497,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         unsigned long long* g = g_conv_stamps[blockIdx.x];
-        g[0] = st_begin; g[1] = st_loop; g[2] = st_epi; g[3] = HD_STAMP(); g[4] = st_bar; g[5] = ((unsigned long long)xcc << 32) | hwid;
+        g[0] = st_begin; g[1] = st_loop; g[2] = st_epi; g[3] = HD_STAMP(); g[4] = st_bar; g[5] = ((unsigned long long)xcc << 32) | hwid; g[6] = st_issue - st_begin; g[7] = st_arrive - st_issue; g[8] = st_a - st_begin; g[9] = st_b - st_a; g[10] = st_c - st_b; g[11] = st_d - st_c;
     }
 #endif
 }

@@ -57,14 +57,16 @@ def main():
     if hasattr(lib, "hd_debug_conv_stamps") and not (a.mode & 256):     # make EXTRA=-DHD_STAMPS: per-workgroup cycle stamps of the implicit-GEMM kernel
         import numpy as np
         nwg = 4096
-        buf = (C.c_ulonglong * (6 * nwg))()
+        buf = (C.c_ulonglong * (12 * nwg))()
         if lib.hd_debug_conv_stamps(buf, nwg) == 0:
-            sa = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 6).astype(np.int64)
+            sa = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 12).astype(np.int64)
             sa = sa[sa[:, 3] > 0]
             pro, loop, epi, bar = sa[:, 1] - sa[:, 0], sa[:, 2] - sa[:, 1], sa[:, 3] - sa[:, 2], sa[:, 4]
             print(f"  stamps over {len(sa)} workgroups (cycles of wave 0, mean / p10 / p90): prologue {pro.mean():.0f} / {np.percentile(pro, 10):.0f} / {np.percentile(pro, 90):.0f}"
                   f"   loop {loop.mean():.0f} / {np.percentile(loop, 10):.0f} / {np.percentile(loop, 90):.0f} (of which in barriers {bar.mean():.0f})"
                   f"   epilogue {epi.mean():.0f} / {np.percentile(epi, 10):.0f} / {np.percentile(epi, 90):.0f}")
+            print(f"  inside the prologue (mean cycles): entry -> first window's loads issued {sa[:, 6].mean():.0f}, until they arrive {sa[:, 7].mean():.0f}"
+                  f"   [entry -> tile decoded {sa[:, 8].mean():.0f}, tables written {sa[:, 9].mean():.0f}, first barrier {sa[:, 10].mean():.0f}, items set up {sa[:, 11].mean():.0f}]")
             ebuf = (C.c_ulonglong * (3 * nwg))()
             if hasattr(lib, "hd_debug_conv_epi_stamps") and lib.hd_debug_conv_epi_stamps(ebuf, nwg) == 0:
                 e = np.frombuffer(ebuf, dtype=np.uint64).reshape(nwg, 3).astype(np.int64)
