@@ -91,7 +91,10 @@ def max_over_ranks(seconds, dist, device):
 
 
 def host_threads():
-    """CPU-baseline threads: the cores this job may use, capped at the GPU box's share of 16 per GPU (HICDIFF_CPU_THREADS overrides)."""
+    """CPU-baseline threads.  BASELINE.md section 3 asks for the box's host cores; a GPU box SHOWS every core of its host (os.cpu_count() = 128
+    or more) but grants one job a share of 16 per GPU, and torch on one thread per visible core crawls under that oversubscription (measured:
+    slower than 16 threads).  So: the cores this job may use (scheduler affinity), capped at that share of 16; HICDIFF_CPU_THREADS overrides
+    the cap.  The JSON line carries both figures (`cores` = threads used, `host_cpu_count` = os.cpu_count())."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
@@ -152,7 +155,7 @@ def cpu_baseline(w, budget_s=20.0):
             break
     sec_per_step = el / n
     return {
-        "value": bs / (T_CHAIN * sec_per_step), "unit": "tiles/s", "cores": cores, "kind": "port",
+        "value": bs / (T_CHAIN * sec_per_step), "unit": "tiles/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
         "sample": f"{n} reverse steps (eps-net + posterior update) of the same {w['arch']} on {bs} tiles of "
                   f"1x{w['S']}x{w['S']}, torch CPU fp32 oracle, {cores} threads; scaled to a {T_CHAIN}-step chain",
     }

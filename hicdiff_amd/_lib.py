@@ -32,16 +32,29 @@ class HdNamedTensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
 
 
-class HdDdpmCoef(C.Structure):
+HD_ABI_VERSION = 3      # include/hicdiff_hip.h; checked against hd_abi_version() in load()
+
+
+class _Prefixed(C.Structure):
+    """Size-prefixed struct of the ABI: `struct_bytes` (first field) is filled in on construction."""
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        self.struct_bytes = C.sizeof(type(self))
+
+
+class HdDdpmCoef(_Prefixed):
     _fields_ = [
+        ("struct_bytes", C.c_uint32),
         ("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
         ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
         ("sigma", C.c_float), ("time_value", C.c_float), ("eps_coef", C.c_float),
     ]
 
 
-class HdDdrmCoef(C.Structure):
+class HdDdrmCoef(_Prefixed):
     _fields_ = [
+        ("struct_bytes", C.c_uint32),
         ("sqrt_at", C.c_float), ("sqrt_1m_at", C.c_float), ("sqrt_at_next", C.c_float), ("sigma_next", C.c_float),
         ("sigma_0", C.c_float), ("etaA", C.c_float), ("etaB", C.c_float), ("etaC", C.c_float), ("time_value", C.c_float),
     ]
@@ -59,6 +72,7 @@ SYMBOLS = {
     "hd_destroy": (None, [_P]),
     "hd_last_error": (C.c_char_p, [_P]),
     "hd_version": (C.c_char_p, []),
+    "hd_abi_version": (C.c_int, []),
     "hd_load_weights": (C.c_int, [_P, C.POINTER(HdNamedTensor), C.c_int, _P]),
     "hd_reserve": (C.c_int, [_P, C.c_int, C.c_int]),
     "hd_workspace_bytes": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_size_t)]),
@@ -111,6 +125,9 @@ def load() -> C.CDLL:
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype, fn.argtypes = res, args
+    if lib.hd_abi_version() != HD_ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI revision {lib.hd_abi_version()}, this binding is written for {HD_ABI_VERSION}: rebuild "
+                           "the library (make -C hicdiff_amd/csrc)")
     _lib = lib
     return lib
 

@@ -41,14 +41,3 @@ int launch_conv_bf16x3_ck32(ConvLaunch& L, hipStream_t st) {
         default: return launch_mode<IN_NONE>(L, st);
     }
 }
-
-#ifdef HD_STAMPS
-extern "C" int hd_debug_conv_stamps(unsigned long long* out, int nwg) {
-    if (nwg < 1 || nwg > 4096) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_stamps), sizeof(unsigned long long) * 12 * nwg) == hipSuccess ? 0 : -3;
-}
-extern "C" int hd_debug_conv_epi_stamps(unsigned long long* out, int nwg) {
-    if (nwg < 1 || nwg > 4096) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_conv_epi_stamps), sizeof(unsigned long long) * 3 * nwg) == hipSuccess ? 0 : -3;
-}
-#endif

@@ -45,7 +45,8 @@
 // make EXTRA=-DHD_STAMPS: wave 0 of every workgroup below 4096 leaves cycle stamps (start, loop entry, loop exit, end, cycles spent in the
 // loop's barriers, XCC / CU id) in a device array that tools/conv_probe.py prints -- a timing study, never part of the product build.
 #ifdef HD_STAMPS
-static __device__ unsigned long long g_conv_stamps[4096][12];   // [6]: cycles from kernel entry to the first window's loads being issued; [7]: from there until they have arrived (s_waitcnt vmcnt(0))
+// p.stamps: [4096][16] device words shared by every translation unit (conv_host.hip owns it).  [6]: cycles from kernel entry to the first
+// window's loads being issued; [7]: from there until they have arrived (s_waitcnt vmcnt(0)); [12..14]: the epilogue's three figures
 #define HD_STAMP() __builtin_readcyclecounter()
 #endif
 
@@ -145,18 +146,6 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     int cb = 0;
     if constexpr (NTAPS == 9) {
         if (p.ksplit > 1) { cb = blockIdx.y * p.kchunks; p.out += (size_t)blockIdx.y * p.split_stride; }
-    }
-    if (p.stagger) {
-        const int mode = p.stagger >> 16, n = p.stagger & 0xffff, b = blockIdx.x;
-        if (mode == 4) {
-            // sixteen start phases spread over the first round (the workgroups of an XCD are b = xcd + 8 j): j and j + 32 -- the two slots
-            // of a CU if the dispatcher fills the CUs in order -- half a cycle apart; n = cycles / 64 of one phase step
-            const int j = b >> 3, phase = (j + ((j >> 5) & 1) * 8) & 15;
-            if (b < 512) for (int i = 0; i < phase * n; ++i) __builtin_amdgcn_s_sleep(1);
-        } else {
-            const bool hit = b < 512 && (mode == 1 ? (b >> 8) & 1 : mode == 2 ? b & 1 : (b >> 3) & 1);
-            if (hit) for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-        }
     }
 
     // ---- parameter table: thread tid < n4 owns entry tid = (sample tid / (CK/4), channels 4 * (tid % (CK/4)))
@@ -496,7 +485,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* g = g_conv_stamps[blockIdx.x];
+        unsigned long long* g = p.stamps + 16 * blockIdx.x;
         g[0] = st_begin; g[1] = st_loop; g[2] = st_epi; g[3] = HD_STAMP(); g[4] = st_bar; g[5] = ((unsigned long long)xcc << 32) | hwid; g[6] = st_issue - st_begin; g[7] = st_arrive - st_issue; g[8] = st_a - st_begin; g[9] = st_b - st_a; g[10] = st_c - st_b; g[11] = st_d - st_c;
     }
 #endif

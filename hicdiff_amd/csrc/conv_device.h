@@ -25,7 +25,9 @@ struct ConvKArgs {
     int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
     int plain;    // bf16x3 kernel family: 1 = one bf16 MFMA per product (training's optional bf16 arithmetic; 8-wave 3x3 variant only)
-    int stagger;  // experiment (HICDIFF_STAGGER = mode*65536 + sleep units): delay half of the first wave of workgroups
+#ifdef HD_STAMPS
+    unsigned long long* stamps;   // timing study builds only (make EXTRA=-DHD_STAMPS): [4096][16] cycle stamps, see conv_bf16x3_kernel.h
+#endif
     int ablate;   // timing experiments only (HICDIFF_ABLATE): 1 no epilogue stores, 2 no X staging, 4 no W staging, 8 no MFMA
 };
 
@@ -157,9 +159,6 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 //   stage: LDS, BM x (BN + 4) floats, overlays the operand buffers (all MFMA reads are done).
 //   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
 //   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
-#ifdef HD_STAMPS
-static __device__ unsigned long long g_conv_epi_stamps[4096][3];   // per workgroup (wave 0), cycles inside the epilogue's barriers / LDS staging writes / row passes with their stores
-#endif
 template <int BM, int BN, int TM, int TN, int NT>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
                                               const int* rowb, float* stage) {
@@ -277,7 +276,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                         const f32x4 o4 = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { const float x = live ? o4[j] : 0.f; s1[0][j] += x; s2[0][j] = __builtin_fmaf(x, x, s2[0][j]); }
-                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)(pix * p.Cout)) = o4;
+                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)pix * (unsigned)p.Cout) = o4;
                     }
                 } else {
 #pragma unroll
@@ -293,7 +292,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                             const float x = live ? o4[j] : 0.f, lo = up ? 0.f : x, hi = up ? x : 0.f;
                             s1[0][j] += lo; s2[0][j] = __builtin_fmaf(lo, lo, s2[0][j]); s1[1][j] += hi; s2[1][j] = __builtin_fmaf(hi, hi, s2[1][j]);
                         }
-                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)(pix * p.Cout)) = o4;
+                        if (live && keep) *reinterpret_cast<f32x4*>(obase + (unsigned)pix * (unsigned)p.Cout) = o4;
                     }
                 }
             } else if (vec) {
@@ -435,7 +434,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
     }
 #ifdef HD_STAMPS
     if (t.tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
-        g_conv_epi_stamps[blockIdx.x][0] = e_bar; g_conv_epi_stamps[blockIdx.x][1] = e_stage; g_conv_epi_stamps[blockIdx.x][2] = e_store;
+        unsigned long long* g = p.stamps + 16 * blockIdx.x;     // per workgroup (wave 0): cycles inside the epilogue's barriers / LDS staging writes / row passes with their stores
+        g[12] = e_bar; g[13] = e_stage; g[14] = e_store;
     }
 #endif
 }

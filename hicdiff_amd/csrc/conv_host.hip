@@ -187,14 +187,32 @@ static bool gn_in_epilogue(const ConvPlan& pl) {
 static int g_wino_mode = -1;           // -1: environment, 0: off, 1: on
 void conv_set_winograd(int mode) { g_wino_mode = mode; }
 bool conv_uses_winograd(const ConvArgs& a) {
-    static const bool env_on = getenv("HICDIFF_WINOGRAD") && atoi(getenv("HICDIFF_WINOGRAD")) != 0;
-    const bool on = g_wino_mode < 0 ? env_on : g_wino_mode != 0;
-    if (!on || a.precision != HD_PREC_BF16X3 || !a.cw.wino || a.cw.KH != 3 || a.cw.KW != 3 || a.stride != 1 || a.pad != 1) return false;
+    if (!conv_winograd_enabled() || a.precision != HD_PREC_BF16X3 || !a.cw.wino || a.cw.KH != 3 || a.cw.KW != 3 || a.stride != 1 || a.pad != 1) return false;
     if (a.H % 16 || a.W % 16 || a.C0 % 16 || a.C1 % 16 || a.cw.CoutPad % 64 || a.cw.Cout % 4 || a.w_bstride || a.plain_bf16) return false;
     if (a.in_mode != IN_NONE && a.in_mode != IN_AFFINE_SILU) return false;
     if (a.ep & ~(EP_FILM_SILU | EP_ADD_SILU | EP_RES)) return false;
     return a.upsample ? (a.IH * 2 == a.H && a.IW * 2 == a.W) : (a.IH == a.H && a.IW == a.W);
 }
+
+bool conv_winograd_enabled() {
+    static const bool env_on = getenv("HICDIFF_WINOGRAD") && atoi(getenv("HICDIFF_WINOGRAD")) != 0;
+    return g_wino_mode < 0 ? env_on : g_wino_mode != 0;
+}
+
+#ifdef HD_STAMPS
+// timing-study builds: one stamp array for the kernels of every translation unit, [4096 workgroups][16 words]
+static unsigned long long* g_stamps = nullptr;
+static unsigned long long* conv_stamps_buffer() {
+    if (!g_stamps && (hipMalloc((void**)&g_stamps, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess || hipMemset(g_stamps, 0, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess)) g_stamps = nullptr;
+    return g_stamps;
+}
+extern "C" int hd_debug_conv_stamps(unsigned long long* out, int nwg, int clear) {     // out: [nwg][16] host words
+    if (nwg < 1 || nwg > 4096 || !g_stamps) return -1;
+    if (hipMemcpy(out, g_stamps, sizeof(unsigned long long) * 16 * nwg, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    if (clear && hipMemset(g_stamps, 0, 4096 * 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    return 0;
+}
+#endif
 
 int conv_splitk(const ConvArgs& a) {
     static const int forced = getenv("HICDIFF_SPLITK") ? atoi(getenv("HICDIFF_SPLITK")) : -1;
@@ -269,8 +287,12 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.plain = a.plain_bf16;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
-    static const int stagger = getenv("HICDIFF_STAGGER") ? atoi(getenv("HICDIFF_STAGGER")) : 0;
-    k.stagger = stagger;
+#ifdef HD_STAMPS
+    k.stamps = conv_stamps_buffer();
+    if (!k.stamps) { hd_set_error("conv: stamp buffer allocation failed"); return -3; }
+#endif
+    // the epilogue's fast path forms 32-bit element offsets (conv_device.h)
+    if ((long long)a.B * a.H * a.W * a.cw.Cout >= (1LL << 31)) { hd_set_error("conv: output tensors of 2^31 elements or more are not supported (cut the batch)"); return -1; }
     if (conv_uses_winograd(a)) {
         if (k.Cin != a.cw.Cin) { hd_set_error("conv: channel counts do not match the packed weight"); return -1; }
         k.tiles_y = a.H / 16; k.tiles_x = a.W / 16; k.ntiles_n = k.CoutPad / 64;

@@ -145,6 +145,7 @@ int hd_ddrm_general_update(const float* vt_x0, const float* vt_et, const float* 
                            const float* z1, const float* z2, const hd_ddrm_coef* c, float* out, int B, int D, uint64_t seed,
                            uint64_t tile_offset, uint32_t step, void* stream) {
     if (!vt_x0 || !vt_et || !out || !c || B < 1 || D < 4 || D % 4 || M < 0 || M > D || (M > 0 && (!ut_y || !singulars))) return HD_EINVAL;
+    if (c->struct_bytes != sizeof(hd_ddrm_coef)) { hd_set_error("hd_ddrm_coef: struct_bytes must be sizeof(hd_ddrm_coef)"); return HD_EINVAL; }   // size-prefixed struct (hicdiff_hip.h)
     hipLaunchKernelGGL(ddrm_general_update_kernel, dim3((unsigned)(((size_t)B * (D / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vt_x0, vt_et,
                        ut_y, singulars, M, D, z0, z1, z2, c->sigma_next, c->sigma_0, c->etaA, c->etaB, c->etaC, c->sqrt_at_next, out, B, seed,
                        tile_offset, step);

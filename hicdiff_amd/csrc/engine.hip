@@ -115,7 +115,7 @@ struct hd_ctx {
     int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
     // hipGraph replay of the fused sampler steps (device-generated noise only): one graph per
     // (kind, B, S, tensor addresses); the step's scalars are written to `sp_dev` by a 1-thread kernel.
-    struct StepGraph { int kind, B, S; const void *x, *aux, *x0; int seen; hipGraphExec_t exec; };
+    struct StepGraph { int kind, B, S, precision; const void *x, *aux, *x0; int seen; hipGraphExec_t exec; };
     std::vector<StepGraph> graphs;
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -192,7 +192,10 @@ struct Loader {
             }
         }
         HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, w->ck, st));
-        if (KH == 3 && !unshuffle && cin % 16 == 0 && cout % 4 == 0) {      // Winograd image of the 3x3 filters (conv_winograd.hip)
+        // Winograd image of the 3x3 filters (conv_winograd.hip): only while that opt-in path is switched on (HICDIFF_WINOGRAD=1 / hd_debug_winograd(1)
+        // before the weights are loaded) -- the image is 16/9 of the filter bytes twice over and one more pack launch per layer; without it
+        // conv_uses_winograd() is false and the layer takes the implicit-GEMM kernel
+        if (conv_winograd_enabled() && KH == 3 && !unshuffle && cin % 16 == 0 && cout % 4 == 0) {
             if (!w->wino) {
                 void* p = nullptr;
                 if (hipMalloc(&p, conv_winograd_weight_bytes(cin, w->CoutPad)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
@@ -718,10 +721,27 @@ static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float t
     return rc;
 }
 
+// A size-prefixed struct of the ABI (include/hicdiff_hip.h) -> a zero-filled copy of this build's revision.  Exactly `struct_bytes` bytes of
+// the caller's memory are read; sizes this build does not know -- a struct from a binding without the prefix shows up here as the bit
+// pattern of its first float -- are refused, never read past.
+template <typename T>
+static bool read_prefixed(const T* src, size_t oldest_bytes, T* dst) {
+    uint32_t n;
+    memcpy(&n, src, sizeof(n));
+    if (n < oldest_bytes || n > sizeof(T) || n % 4) return false;
+    memset(dst, 0, sizeof(T));
+    memcpy(dst, src, n);
+    return true;
+}
+static const char* const kCoefSizeMsg =
+    "coefficient struct: struct_bytes is not a size this library knows (set it to sizeof of your struct; bindings written before ABI revision 3 "
+    "lack the field -- see include/hicdiff_hip.h)";
+
 // ---- C ABI -------------------------------------------------------------------------------------
 extern "C" {
 
-const char* hd_version(void) { return "hicdiff_hip 0.1 (gfx950, fp32 MFMA)"; }
+const char* hd_version(void) { return "hicdiff_hip 0.3 (gfx950; split-bf16 x3 / exact fp32 MFMA)"; }
+int hd_abi_version(void) { return HD_ABI_VERSION; }
 
 const char* hd_last_error(const hd_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -843,13 +863,13 @@ static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float
             return fail(c, HD_EHIP, "graph stream setup failed");
     }
     hd_ctx::StepGraph* g = nullptr;
-    for (auto& e : c->graphs) if (e.kind == kind && e.B == B && e.S == S && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
+    for (auto& e : c->graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == c->precision && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
     if (!g) {
         if (c->graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
             if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec);
             c->graphs.erase(c->graphs.begin());
         }
-        c->graphs.push_back({kind, B, S, x, aux, x0_out, 0, nullptr});
+        c->graphs.push_back({kind, B, S, c->precision, x, aux, x0_out, 0, nullptr});
         g = &c->graphs.back();
     }
     // order after the caller's stream, run on the engine's capturable stream, hand back
@@ -876,9 +896,11 @@ static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float
     return rc;
 }
 
-int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, const hd_ddpm_coef* k, float* x0_out, int B, int S,
+int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, const hd_ddpm_coef* kin, float* x0_out, int B, int S,
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
-    if (!c || !x || !k) return HD_EINVAL;
+    if (!c || !x || !kin) return HD_EINVAL;
+    hd_ddpm_coef kk, *k = &kk;
+    if (!read_prefixed(kin, offsetof(hd_ddpm_coef, eps_coef), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);   // (without eps_coef: an ancestral step)
     if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
     if ((c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
     StepParams v{};
@@ -888,9 +910,11 @@ int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, con
     return keep_err(c, run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream));
 }
 
-int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_ddrm_coef* k, float* x0_out, int B, int S,
+int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_ddrm_coef* kin, float* x0_out, int B, int S,
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
-    if (!c || !x || !y || !k) return HD_EINVAL;
+    if (!c || !x || !y || !kin) return HD_EINVAL;
+    hd_ddrm_coef kk, *k = &kk;
+    if (!read_prefixed(kin, sizeof(hd_ddrm_coef), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);
     if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
     StepParams v{};
     v.f[0] = k->time_value; v.f[1] = k->sqrt_at; v.f[2] = k->sqrt_1m_at; v.f[3] = k->sqrt_at_next; v.f[4] = k->sigma_next;
@@ -945,13 +969,8 @@ int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {
     if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3)) return HD_EINVAL;
-    if (mode != c->precision && !c->graphs.empty()) {
-        // a captured step holds the kernels of the arithmetic it was captured under: drop them with the mode
-        if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
-        if (c->gstream && hipStreamSynchronize(c->gstream) != hipSuccess) return fail(c, HD_EHIP, "stream synchronize failed");
-        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        c->graphs.clear();
-    }
+    // a captured step holds the kernels of the arithmetic it was captured under: the graph cache is keyed by the mode (run_step), so a
+    // sampler that switches back and forth (ddim_sample runs exact fp32) keeps both sets instead of re-capturing every time
     c->precision = mode;
     return HD_OK;
 }

@@ -105,6 +105,7 @@ size_t conv_winograd_weight_bytes(int Cin, int CoutPad);
 int launch_pack_winograd(const float* packed, unsigned short* dst, int Cin, int CoutPad, hipStream_t st);   // packed: fp32 [9][Cin][CoutPad]
 bool conv_uses_winograd(const ConvArgs& a);   // a.precision must be set
 void conv_set_winograd(int mode);             // -1: HICDIFF_WINOGRAD decides (default off), 0: off, 1: on
+bool conv_winograd_enabled();                 // the switch as it stands now (hd_load_weights packs the Winograd filter images only while it is on)
 int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st);
 
 int launch_conv_small_cin(const float* x, const float* cond, const float* w, const float* bias, float* out,

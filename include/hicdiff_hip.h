@@ -73,9 +73,19 @@ typedef struct {
     int64_t shape[4];
 } hd_named_tensor;
 
+/* ABI revision of this header.  hd_abi_version() returns the revision the library was built from: a binding checks it once after
+ * loading.  Revision 3 (round 3) put `struct_bytes` in front of the two per-step coefficient structs.
+ *
+ * Size-prefixed structs.  The caller stores sizeof(its own struct) in `struct_bytes`; the library copies that many bytes (never more)
+ * into a zeroed struct of its own revision, so a caller built against an OLDER revision of a struct keeps working (the fields it does
+ * not know read as 0) and a struct from a binding that predates the prefix, or any other size the library does not know, is refused
+ * with HD_EINVAL instead of being read past its end. */
+#define HD_ABI_VERSION 3
+
 /* Coefficients of one ancestral reverse step, gathered by the host from the 13 schedule buffers of
  * GaussianDiffusion.__init__ (src/hicdiff.py:494-522) at index t. */
 typedef struct {
+    uint32_t struct_bytes;               /* = sizeof(hd_ddpm_coef) of the caller's header (32 in revision 3; 28 = a revision-3 struct without eps_coef is accepted) */
     float sqrt_recip_alphas_cumprod;     /* predict_start_from_noise, src/hicdiff.py:529-533 */
     float sqrt_recipm1_alphas_cumprod;
     float posterior_mean_coef1;          /* q_posterior, src/hicdiff.py:553-560 */
@@ -88,6 +98,7 @@ typedef struct {
 
 /* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
 typedef struct {
+    uint32_t struct_bytes;  /* = sizeof(hd_ddrm_coef) (40 in revision 3) */
     float sqrt_at;          /* sqrt(alpha_bar_t) */
     float sqrt_1m_at;       /* sqrt(1 - alpha_bar_t) */
     float sqrt_at_next;     /* sqrt(alpha_bar_next) */
@@ -103,6 +114,7 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* arch);
 void hd_destroy(hd_ctx* ctx);
 const char* hd_last_error(const hd_ctx* ctx);
 const char* hd_version(void);
+int hd_abi_version(void);   /* HD_ABI_VERSION of the build */
 
 /* load_state_dict (train.py:186, inference.py:93,104): validates names/shapes against the
  * architecture, weight-standardises the UNet's 3x3 convs once (src/hicdiff.py:84-97 recomputes it

@@ -78,7 +78,8 @@ int hd_debug_attn_full_bwd(const float* qkv, const float* dout, int B, int n, in
 int hd_debug_linattn_bwd(const float* qkv, const float* dout, int B, int n, int heads, float* dqkv, void* stream);
 
 /* The Winograd F(2x2,3x3) form of the eligible 3x3 convolutions (csrc/conv_winograd.hip) is opt-in: 1 = on, 0 = off, -1 = as the
- * environment says (HICDIFF_WINOGRAD, default off).  Process-wide; contexts pack the Winograd filter image at hd_load_weights either way. */
+ * environment says (HICDIFF_WINOGRAD, default off).  Process-wide; a context packs the Winograd filter images at hd_load_weights only while
+ * the switch is on, so turn it on BEFORE loading the weights (layers without the image take the implicit-GEMM kernel). */
 int hd_debug_winograd(int mode);
 
 /* Enable capture (1) / disable and drop captures (0) of labelled intermediates of later forwards. */

@@ -132,7 +132,14 @@ def main(argv=None):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.data_root:
-        return run_test_split(args, conditional, device)
+        # The evaluation harness (VisionMetrics.getMetrics, upstream a single-process flow) prepares the Splits/ files and writes one set of
+        # Outputs_diff/<name>/*.npy: under torchrun it runs on rank 0 only -- every rank running it would race on those files -- and the other
+        # ranks wait at the common barrier.  (Sharded sampling of a tile list is the path below: --noisy / --matrix / --synthetic.)
+        predict = run_test_split(args, conditional, device) if rank == 0 else None
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return predict
     origins = None
     if args.matrix:
         from hicdiff_amd.processdata import split_pieces_device

@@ -57,29 +57,26 @@ def main():
     if hasattr(lib, "hd_debug_conv_stamps") and not (a.mode & 256):     # make EXTRA=-DHD_STAMPS: per-workgroup cycle stamps of the implicit-GEMM kernel
         import numpy as np
         nwg = 4096
-        buf = (C.c_ulonglong * (12 * nwg))()
-        if lib.hd_debug_conv_stamps(buf, nwg) == 0:
-            sa = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 12).astype(np.int64)
+        buf = (C.c_ulonglong * (16 * nwg))()
+        if lib.hd_debug_conv_stamps(buf, nwg, 1) == 0:
+            sa = np.frombuffer(buf, dtype=np.uint64).reshape(nwg, 16).astype(np.int64)
             sa = sa[sa[:, 3] > 0]
-            pro, loop, epi, bar = sa[:, 1] - sa[:, 0], sa[:, 2] - sa[:, 1], sa[:, 3] - sa[:, 2], sa[:, 4]
-            print(f"  stamps over {len(sa)} workgroups (cycles of wave 0, mean / p10 / p90): prologue {pro.mean():.0f} / {np.percentile(pro, 10):.0f} / {np.percentile(pro, 90):.0f}"
-                  f"   loop {loop.mean():.0f} / {np.percentile(loop, 10):.0f} / {np.percentile(loop, 90):.0f} (of which in barriers {bar.mean():.0f})"
-                  f"   epilogue {epi.mean():.0f} / {np.percentile(epi, 10):.0f} / {np.percentile(epi, 90):.0f}")
-            print(f"  inside the prologue (mean cycles): entry -> first window's loads issued {sa[:, 6].mean():.0f}, until they arrive {sa[:, 7].mean():.0f}"
-                  f"   [entry -> tile decoded {sa[:, 8].mean():.0f}, tables written {sa[:, 9].mean():.0f}, first barrier {sa[:, 10].mean():.0f}, items set up {sa[:, 11].mean():.0f}]")
-            ebuf = (C.c_ulonglong * (3 * nwg))()
-            if hasattr(lib, "hd_debug_conv_epi_stamps") and lib.hd_debug_conv_epi_stamps(ebuf, nwg) == 0:
-                e = np.frombuffer(ebuf, dtype=np.uint64).reshape(nwg, 3).astype(np.int64)
-                e = e[e.sum(axis=1) > 0]
-                print(f"  inside the epilogue (mean cycles): barriers {e[:, 0].mean():.0f}, accumulators -> LDS {e[:, 1].mean():.0f}, row passes + stores {e[:, 2].mean():.0f}")
-            # timeline of a few CUs (a CU's workgroups share a cycle counter; HW_ID bits 8-15 = CU / SH / SE): start, loop entry,
-            # epilogue entry and end of each of its workgroups, in thousands of cycles from the CU's first start
-            key = ((sa[:, 5] >> 32) << 8) | ((sa[:, 5] & 0xffff) >> 8)
-            for k in np.unique(key)[:3]:
-                c = sa[key == k]
-                c = c[np.argsort(c[:, 0])]
-                t0 = c[0, 0]
-                print(f"  CU {int(k):#x}: {len(c)} workgroups; " + "  ".join(f"[{(r[0]-t0)/1e3:.0f} {(r[1]-t0)/1e3:.0f} {(r[2]-t0)/1e3:.0f} {(r[3]-t0)/1e3:.0f}]" for r in c))
+            if len(sa):
+                pro, loop, epi, bar = sa[:, 1] - sa[:, 0], sa[:, 2] - sa[:, 1], sa[:, 3] - sa[:, 2], sa[:, 4]
+                print(f"  stamps over {len(sa)} workgroups (cycles of wave 0, mean / p10 / p90): prologue {pro.mean():.0f} / {np.percentile(pro, 10):.0f} / {np.percentile(pro, 90):.0f}"
+                      f"   loop {loop.mean():.0f} / {np.percentile(loop, 10):.0f} / {np.percentile(loop, 90):.0f} (of which in barriers {bar.mean():.0f})"
+                      f"   epilogue {epi.mean():.0f} / {np.percentile(epi, 10):.0f} / {np.percentile(epi, 90):.0f}")
+                print(f"  inside the prologue (mean cycles): entry -> first window's loads issued {sa[:, 6].mean():.0f}, until they arrive {sa[:, 7].mean():.0f}"
+                      f"   [entry -> tile decoded {sa[:, 8].mean():.0f}, tables written {sa[:, 9].mean():.0f}, first barrier {sa[:, 10].mean():.0f}, items set up {sa[:, 11].mean():.0f}]")
+                print(f"  inside the epilogue (mean cycles): barriers {sa[:, 12].mean():.0f}, accumulators -> LDS {sa[:, 13].mean():.0f}, row passes + stores {sa[:, 14].mean():.0f}")
+                # timeline of a few CUs (a CU's workgroups share a cycle counter; HW_ID bits 8-15 = CU / SH / SE): start, loop entry,
+                # epilogue entry and end of each of its workgroups, in thousands of cycles from the CU's first start
+                key = ((sa[:, 5] >> 32) << 8) | ((sa[:, 5] & 0xffff) >> 8)
+                for k in np.unique(key)[:3]:
+                    c = sa[key == k]
+                    c = c[np.argsort(c[:, 0])]
+                    t0 = c[0, 0]
+                    print(f"  CU {int(k):#x}: {len(c)} workgroups; " + "  ".join(f"[{(r[0]-t0)/1e3:.0f} {(r[1]-t0)/1e3:.0f} {(r[2]-t0)/1e3:.0f} {(r[3]-t0)/1e3:.0f}]" for r in c))
     if hasattr(lib, "hd_debug_wino_stamps"):           # DIAG builds: in-kernel cycle stamps of one workgroup (conv_winograd.hip)
         buf = (C.c_ulonglong * 16)()
         if lib.hd_debug_wino_stamps(buf) == 0:
