@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhicdiff_hip.so")
+# HICDIFF_HIP_LIB: another build of the same library (experiment builds, `make TAG=_x EXTRA=-D...` -> libhicdiff_hip_x.so); never a fallback
+LIB_PATH = os.environ.get("HICDIFF_HIP_LIB") or os.path.join(_HERE, "libhicdiff_hip.so")
 
 HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -4, -5
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1

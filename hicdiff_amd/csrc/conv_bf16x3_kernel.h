@@ -5,22 +5,32 @@
 // Dropped terms are O(2^-17) relative: ~2e-5 error on an epsilon forward, 1e-4 on a 50-step chain
 // (plain bf16 operands give 1e-2 and fail the 1e-3 parity bound).
 //
-// LDS rows (one staged pixel of X / one output channel of W) are [CK bf16 hi | CK bf16 lo | 16 B pad];
-// the pitch 4*CK+16 bytes is an odd multiple of 16, so the 16 lanes of a ds_read_b128 group (16
-// consecutive pixels / channels) hit 16 different 16-byte bank slots.  Weights arrive pre-split
-// ([tap][Cin/CK][CoutPad][hi|lo], packed at load time) and are copied 16 bytes per lane; activations
-// are split on the fly while the loader applies its transform.
+// LDS images.  Activations: one row per staged pixel, [CK bf16 hi | CK bf16 lo | 16 B pad]; the pitch 4*CK+16 bytes is an odd multiple
+// of 16, so the 16 lanes of a ds_read_b128 group (16 consecutive pixels) hit 16 different 16-byte bank slots.  They are split on the fly
+// while the loader applies its transform.  Weights: the global image is ALWAYS packed in 16-channel steps,
+// [tap][Cin/16][CoutPad][16 hi | 16 lo] (64-byte rows, split once at load time), whatever the kernel's activation slice CK is, so the
+// weights of one MFMA k-step -- a "k16-slab", BN rows of 64 bytes -- are one contiguous block.  In LDS a k16-slab is UNPADDED: piece pc
+// (16 bytes) of row n sits at n*64 + ((pc ^ ((n >> 2) & 3)) << 4); the rows a ds_read_b128 lane group touches are distinct modulo 16, so
+// the XOR spreads them over the 16 bank slots (checked for the 32x32x16 and the 16x16x32 operand maps).  The workgroup keeps a RING of
+// 2*KS k16-slabs (KS = CK/16 k-steps per tap): the same bytes as two padded slabs took, minus the padding.
 //
-// Pipeline.  One iteration per (K slice c, filter tap), ONE barrier each.  After the barrier, in program order:
-//   1. weight slab it+1: prefetch registers -> the LDS buffer slab it-1 was read from; a later slab is requested into the
-//      registers just freed (3x3 kernels keep three register sets in flight: slab it+4; the any-filter kernels one: slab it+2);
+// Pipeline of the 3x3 kernels.  One iteration per (K slice c, filter tap), ONE barrier each, fragments read ONE K-STEP AHEAD:
+//   at the barrier of iteration `it` every wave already holds the operand fragments of the tap's first k-step in registers (they were
+//   read from LDS under the MFMAs of iteration it-1; only the window fragments of a slice's first tap cannot be, the window is staged at
+//   the slice switch).  After the barrier, in program order:
+//   1. the weight unit U(it) = k16-slabs KS*it + KS+1 .. KS*it + 2*KS goes from its prefetch registers to the ring slots whose previous
+//      tenants (k16-slabs <= KS*it) every wave has finished reading -- the barrier's lgkmcnt(0) saw to that -- and unit U(it + WD) is
+//      requested into the registers just freed (three register sets in flight: WD = 3);
 //   2. this tap's share of the raw fp32 values of slice c+1 is requested (registers xr);
-//   3. the MFMA cluster of iteration it.
-// Everything in 1 and 2 is asynchronous, so its latency sits behind the MFMAs instead of in front of a
-// barrier.  The loop body is STRAIGHT-LINE code (taps unrolled, last slice peeled, no data-dependent
-// branch): hipcc places exact s_waitcnt vmcnt(N) only in straight-line code -- with branches between a load
-// and its use it falls back to vmcnt(0), which serialises every load with the MFMA cluster (measured: the
-// kernel then runs at the SUM of its load, staging and MFMA times).
+//   3. per k-step: the NEXT step's fragments are requested (ds_read_b128 into the second fragment set; for a tap's last step they belong
+//      to the next tap: its k16-slab was written during iteration it-1 and became visible at this barrier), then the 12 (6 with TN = 1)
+//      MFMAs of the current step run on fragments that have been in registers since the previous step.
+// So no MFMA waits for an LDS round trip issued in its own step, and everything in 1 and 2 is asynchronous.  The loop body is
+// STRAIGHT-LINE code (taps unrolled, last slice peeled, no data-dependent branch): hipcc places exact s_waitcnt vmcnt(N) only in
+// straight-line code -- with branches between a load and its use it falls back to vmcnt(0), which serialises every load with the MFMA
+// cluster (measured: the kernel then runs at the SUM of its load, staging and MFMA times).
+// The any-filter kernels (1x1, 2x2 stride 2, LayerNorm / softmax loaders: taps in a runtime loop) keep the simpler order: slab it+1 is
+// written during iteration it, fragments are read in the step that uses them.
 // The per-slice operands of the loader transform (GroupNorm/FiLM scale and shift, LayerNorm gain) come from
 // a small double-buffered LDS table filled one slice ahead, so staging a slice touches no global memory.
 // Loader transforms: none, GroupNorm-apply + FiLM + SiLU (+ additive term), channel LayerNorm, softmax over each
@@ -109,31 +119,44 @@ __device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
 // WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread;
 // NTAPS = 9: 3x3 filter, taps unrolled; NTAPS = 0: any filter (1x1, 2x2 stride 2, ...), taps in a loop.
 // PLAIN: one bf16 MFMA per product (hi x hi only) -- the optional bf16 arithmetic of the training step; the staging is unchanged.
+#ifndef HD_CK16_CAP3
+#define HD_CK16_CAP3 1    // 1: the plain-loader 256 x 64 tile with 16-channel slices is capped at 168 registers (three workgroups per CU)
+#endif
+template <int WM, int WN, int CK, int MODE>
+constexpr bool conv_cap3() { return HD_CK16_CAP3 && CK == 16 && WM == 4 && WN == 1 && MODE == IN_NONE; }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
 __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = 4 * CK + 16, ROWB = 4 * CK;
-    constexpr int KS = CK / 16;                        // k16 MFMA steps per slab
+    constexpr bool M16 = CK == 32 && NTAPS == 9 && HD_MFMA16;   // 16 x 16 x 32 MFMA tiles (one instruction covers the whole 32-channel slice); the 1x1 kernels measured 5-12 % slower on it
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = M16 ? 160 : 4 * CK + 16;
+    constexpr int TMF = M16 ? 2 * TM : TM, TNF = M16 ? 2 * TN : TN;   // operand blocks per wave (16 or 32 rows / columns each)
+    constexpr int KS = CK / 16;                        // k16 MFMA steps per tap
     constexpr int IPP = CK / 8;                        // 8-channel items per staged pixel
-    constexpr int NW = (BN * (CK / 4)) / NT;           // 16-byte weight pieces per thread per slab
-    constexpr int SLAB = BN * PITCH;                   // bytes of one weight slab in LDS
+    constexpr int SLAB16 = BN * 64;                    // bytes of one k16-slab (global: contiguous; LDS: one ring slot)
+    constexpr bool GL = NTAPS == 9 && HD_CONV_GLDS;   // weights by LDS-DMA
+    constexpr int GD = KS == 1 ? 2 : HD_GLDS_D;        // LDS-DMA: slabs requested ahead (16-channel slices: taps of 12 MFMAs are too short to cover one DMA's latency)
+    constexpr int RING = (GL ? GD + 1 : 2) * KS;            // ring slots: the slabs (taps) being read, landing and -- with LDS-DMA -- in flight
+    constexpr int NWH = SLAB16 / 16 / NT;              // 16-byte pieces per thread per k16-slab
+    constexpr int NW = NWH * KS;                       // ... per weight unit (one tap's worth)
     constexpr bool XDB = NT == 512 && NTAPS == 9;      // two activation windows
     constexpr int NV = MODE == IN_NONE || MODE == IN_SOFTMAX32 ? 0 : MODE == IN_LAYERNORM ? 1 : MODE == IN_AFFINE_SILU ? 2 : 3;
     static_assert(MODE != IN_SOFTMAX32 || CK == 32, "the softmax loader works on 32-channel slices");
-    static_assert(NW >= 1 && NW <= 4 && (NT == 256 || NT == 512), "bad tile");
+    static_assert(NWH >= 1 && NW <= 4 && SLAB16 % (16 * NT) == 0 && (NT == 256 || NT == 512), "bad tile");
     static_assert(NTAPS == 9 || NTAPS == 0, "taps are unrolled for 3x3 filters only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int npx = p.npx;
     const int npx4 = (npx + 3) & ~3;
-    int* pxsrc = reinterpret_cast<int*>(smem);
-    int* pxb = pxsrc + npx4;
-    int* rowpix = pxb + npx4;
+    // LDS: [rowpix | rowb] (read by the epilogue) [weight ring] [pxsrc | pxb] [parameter table] [window(s)]; the epilogue's staging
+    // area overlays everything from the ring on.  The ring sits at a compile-time offset.
+    int* rowpix = reinterpret_cast<int*>(smem);
     int* rowb = rowpix + BM;
+    char* Ws = reinterpret_cast<char*>(rowb + BM);     // [RING][BN][64], pieces XOR-swizzled
+    int* pxsrc = reinterpret_cast<int*>(Ws + RING * SLAB16);
+    int* pxb = pxsrc + npx4;
     const int n4 = p.pt_n4;                            // 16-byte entries per table vector; entry n4 is a write sink
     const int ptv = (n4 + 1) * 16, pt_stride = NV * ptv;
-    char* ptab = reinterpret_cast<char*>(rowb + BM);   // [2][NV][n4 + 1] float4
-    char* Ws = ptab + 2 * pt_stride;                   // [2][BN][PITCH]
-    char* Xs = Ws + 2 * SLAB;                          // [1 or 2][npx + 1][PITCH]; row npx is a write sink
+    char* ptab = reinterpret_cast<char*>(pxb + npx4);  // [2][NV][n4 + 1] float4
+    char* Xs = ptab + 2 * pt_stride;                   // [1 or 2][npx + 1][PITCH]; row npx is a write sink
     const int xs_stride = XDB ? p.xs_stride : 0;
 
 #ifdef HD_STAMPS
@@ -183,19 +206,38 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     st_b = HD_STAMP();                 // tables written
 #endif
 
-    int aoff[TM], boff[TN];
+    // operand fragment addresses.  A: staged pixel row of GEMM row (wm, tm, lane) + this lane's k half.  B: output channel n of the ring
+    // slot, pieces swizzled: hi piece `half`, lo piece 2 + half, each XOR (n >> 2) & 3.
+    // 16 x 16 x 32 tiles (M16): lane l holds row / column l & 15 and k chunk l >> 4 (8 channels) of the 32: A = bytes 16 * (l >> 4) of the pixel row's
+    // hi (lo: + 64) half -- the 160-byte pitch keeps a 16-row block's reads conflict-free when its staged indices are consecutive modulo 16
+    // (decode_row) --; B = k16-slab (l >> 5) of the tap, piece (l >> 4) & 1 (lo: + 2) of row n, XOR (n >> 2) & 2.
+    int aoff[TMF], boff[TNF];
+    if constexpr (M16) {
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) aoff[tm] = row_px_offset<TM>(p, t, tm) * PITCH + t.half * 16;
+        for (int i = 0; i < TMF; ++i) aoff[i] = row_px_offset_m(p, t, t.wm * 32 * TM + i * 16 + (t.lane & 15)) * PITCH + (t.lane >> 4) * 16;
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) boff[tn] = (t.wn * 32 * TN + tn * 32 + t.l31) * PITCH + t.half * 16;
+        for (int j = 0; j < TNF; ++j) {
+            const int n = t.wn * 32 * TN + j * 16 + (t.lane & 15), ch = t.lane >> 4;
+            boff[j] = (ch >> 1) * SLAB16 + n * 64 + ((((n >> 2) & 2) ^ (ch & 1)) << 4);
+        }
+    } else {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) aoff[tm] = row_px_offset<TM>(p, t, tm) * PITCH + t.half * 16;
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = t.wn * 32 * TN + tn * 32 + t.l31;
+            boff[tn] = n * 64 + ((((n >> 2) & 3) ^ t.half) << 4);
+        }
+    }
 
-    f32x16 acc[TM][TN];
+    using AccT = std::conditional_t<M16, f32x4, f32x16>;
+    AccT acc[TMF][TNF];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TMF; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+        for (int tn = 0; tn < TNF; ++tn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[tm][tn][r] = 0.f;
+            for (int r = 0; r < (M16 ? 4 : 16); ++r) acc[tm][tn][r] = 0.f;
 
     const int ntaps = NTAPS ? NTAPS : p.KH * p.KW, nchunks_tot = p.Cin / CK;
     const int nchunks = (NTAPS == 9 && p.ksplit > 1) ? min(p.kchunks, nchunks_tot - cb) : nchunks_tot, nit = ntaps * nchunks;
@@ -238,48 +280,65 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         }
     }
 
-    // weight-slab prefetch registers: named scalars (an indexed array here is left in scratch by hipcc).
-    // 3x3 kernels keep THREE sets in flight (slab s travels in set s % 3; nine taps per slice make that a
-    // compile-time index): a slab is requested three iterations before it is written to LDS.  The distance
-    // matters twice over: it covers the weights' own L2 latency, and -- vmcnt retiring in issue order -- the wait
-    // for a slab also waits for every activation load issued before that slab was requested, so it is what gives
-    // the (HBM-latency) activation loads their three iterations of runway.
+    // ---- weights.  Prefetch registers are named scalars (an indexed array here is left in scratch by hipcc); one SET holds a weight
+    // unit = KS k16-slabs = NW 16-byte pieces per thread (piece k: k16-slab k / NWH of the unit, bytes (tid + (k % NWH) * NT) * 16 of it).
+    // 3x3 kernels keep THREE sets in flight (unit U(it) travels in set it % 3; nine taps per slice make that a compile-time index): a
+    // unit is requested three iterations before it is written to LDS.  The distance matters twice over: it covers the weights' own L2
+    // latency, and -- vmcnt retiring in issue order -- the wait for a unit also waits for every activation load issued before that unit
+    // was requested, so it is what gives the (HBM-latency) activation loads their three iterations of runway.
     constexpr int WD = NTAPS == 9 && !(NW == 4 && MAXI > 3) ? 3 : 1;   // (the largest-window 128 x 128 variant would lose its second workgroup per CU to the extra registers)
     uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0, v0 = w0, v1 = w0, v2 = w0, v3 = w0, u0 = w0, u1 = w0, u2 = w0, u3 = w0;
-#define HD_WLOAD(S, k)                                                                                     \
-    if constexpr (NW > k) {                                                                                \
-        const int idx = tid + k * NT;                                                                      \
-        const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
-        S##k = *reinterpret_cast<const uint4*>(wsrc + (size_t)row * ROWB + piece * 16);                    \
+    int wdst[NWH];                                     // swizzled LDS offset of this thread's piece(s) inside a ring slot
+#pragma unroll
+    for (int kk = 0; kk < NWH; ++kk) {
+        const int j = tid + kk * NT, row = j >> 2, pc = j & 3;
+        wdst[kk] = row * 64 + ((pc ^ (M16 ? (row >> 2) & 2 : (row >> 2) & 3)) << 4);
     }
-#define HD_WSTORE(S, k)                                                                                    \
-    if constexpr (NW > k) {                                                                                \
-        const int idx = tid + k * NT;                                                                      \
-        const int row = idx / (CK / 4), piece = idx - row * (CK / 4);                                      \
-        *reinterpret_cast<uint4*>(dst + row * PITCH + piece * 16) = S##k;                                  \
-    }
-    // slab k = (slice k / ntaps, tap k % ntaps); weights are stored [tap][slice][CoutPad][ROWB]; with per-sample
+    // k16-slab (slice c, tap, step s) of this workgroup's K range; weights are stored [tap][Cin/16][CoutPad][64 B]; with per-sample
     // weights (w_bstride != 0, one sample per tile) the image of sample b0
-    const char* wbase = reinterpret_cast<const char*>(p.wsplit) + (size_t)t.b0 * p.w_bstride;
-    auto w_load = [&](auto set, int c, int tap) {
+    // LDS-DMA form: one wave-instruction moves 1 KiB = 16 rows; LDS takes it linearly (wave base + lane * 16), so the swizzle is applied to
+    // the SOURCE: lane l fills slot l & 3 of row l >> 2, which must hold piece (l & 3) ^ ((row >> 2) & 3) = (l & 3) ^ ((l >> 4) & 3).
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gl_lane = ((t.lane >> 2) << 6) + (((t.lane & 3) ^ ((t.lane >> 4) & (M16 ? 2 : 3))) << 4);
+    const char* wbase = reinterpret_cast<const char*>(p.wsplit) + (size_t)t.b0 * p.w_bstride + (size_t)t.n0 * 64 + (GL ? gl_lane : tid * 16);
+    const int nch16 = nchunks_tot * KS;
+    auto k16_src = [&](int c, int tap, int s) { return wbase + (size_t)(tap * nch16 + (c + cb) * KS + s) * p.CoutPad * 64; };
+    // slab (c, tap) -> ring slots slot0 .. slot0 + KS - 1, NW wave-instructions per wave, nothing waits here
+    auto w_glds = [&](int c, int tap, int slot0) {
         if (ABL(256)) return;
-        constexpr int S = decltype(set)::value;
-        const char* wsrc = wbase + ((size_t)(tap * nchunks_tot + c + cb) * p.CoutPad + t.n0) * ROWB;
-        if constexpr (S == 0) { HD_WLOAD(w, 0) HD_WLOAD(w, 1) HD_WLOAD(w, 2) HD_WLOAD(w, 3) }
-        else if constexpr (S == 1) { HD_WLOAD(v, 0) HD_WLOAD(v, 1) HD_WLOAD(v, 2) HD_WLOAD(v, 3) }
-        else { HD_WLOAD(u, 0) HD_WLOAD(u, 1) HD_WLOAD(u, 2) HD_WLOAD(u, 3) }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int h = k / NWH, i = (k % NWH) * (NT / 64) + wv;          // k16-slab of the slab, 1 KiB piece inside it
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(k16_src(c, tap, h) + i * 1024),
+                                             (__attribute__((address_space(3))) void*)(Ws + (slot0 + h) * SLAB16 + i * 1024), 16, 0, 0);
+        }
     };
-    auto w_store = [&](auto set, int b) {
-        if (ABL(4)) return;
+#define HD_WLOAD(S, k, src)  if constexpr (NW > k) { if (!ABL(256)) S##k = *reinterpret_cast<const uint4*>((src) + ((k) % NWH) * NT * 16); }
+#define HD_WSTORE(S, k, slot) if constexpr (NW > k) { if (!ABL(4)) *reinterpret_cast<uint4*>(Ws + (slot) * SLAB16 + wdst[(k) % NWH]) = S##k; }
+    // piece k of set S <- k16-slab h = k / NWH of the unit, whose source is src[h] (nullptr: that k16-slab does not exist -- past the end
+    // of the K range; decided at compile time by the callers, so no branch survives)
+    auto w_load = [&](auto set, auto have, const char* s0, const char* s1) {
         constexpr int S = decltype(set)::value;
-        char* dst = Ws + b * SLAB;
-        if constexpr (S == 0) { HD_WSTORE(w, 0) HD_WSTORE(w, 1) HD_WSTORE(w, 2) HD_WSTORE(w, 3) }
-        else if constexpr (S == 1) { HD_WSTORE(v, 0) HD_WSTORE(v, 1) HD_WSTORE(v, 2) HD_WSTORE(v, 3) }
-        else { HD_WSTORE(u, 0) HD_WSTORE(u, 1) HD_WSTORE(u, 2) HD_WSTORE(u, 3) }
+        constexpr int H = decltype(have)::value;      // bit h: k16-slab h of the unit exists
+#define HD_WL(SS, k) if constexpr ((H >> ((k) / NWH)) & 1) { HD_WLOAD(SS, k, ((k) / NWH) ? s1 : s0) }
+        if constexpr (S == 0) { HD_WL(w, 0) HD_WL(w, 1) HD_WL(w, 2) HD_WL(w, 3) }
+        else if constexpr (S == 1) { HD_WL(v, 0) HD_WL(v, 1) HD_WL(v, 2) HD_WL(v, 3) }
+        else { HD_WL(u, 0) HD_WL(u, 1) HD_WL(u, 2) HD_WL(u, 3) }
+#undef HD_WL
+    };
+    auto w_store = [&](auto set, auto have, int slot0, int slot1) {
+        constexpr int S = decltype(set)::value;
+        constexpr int H = decltype(have)::value;
+#define HD_WS(SS, k) if constexpr ((H >> ((k) / NWH)) & 1) { HD_WSTORE(SS, k, ((k) / NWH) ? slot1 : slot0) }
+        if constexpr (S == 0) { HD_WS(w, 0) HD_WS(w, 1) HD_WS(w, 2) HD_WS(w, 3) }
+        else if constexpr (S == 1) { HD_WS(v, 0) HD_WS(v, 1) HD_WS(v, 2) HD_WS(v, 3) }
+        else { HD_WS(u, 0) HD_WS(u, 1) HD_WS(u, 2) HD_WS(u, 3) }
+#undef HD_WS
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
     using S2 = std::integral_constant<int, 2>;
+    using HAll = std::integral_constant<int, (1 << KS) - 1>;
 
     float4 xr[MAXI][2];
     auto x_load = [&](int j, const float* src, int Csrc) {       // src already points at (slice, q8)
@@ -306,33 +365,51 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         const int cc = (c + cb) * CK;
         if (cc < p.C0) { src = p.in0 + cc + q8; Csrc = p.C0; } else { src = p.in1 + (cc - p.C0) + q8; Csrc = p.C1; }
     };
-    auto mfma_cluster = [&](const char* Xc, const char* Wb, int tapoff) {
+
+    // ---- operand fragments: A from the window (pixel rows; k-step s of the slice at byte s*32 of the hi / lo halves), B from ring slot
+    struct FragA { bf16x8 h[TMF], l[TMF]; };
+    struct FragB { bf16x8 h[TNF], l[TNF]; };
+    auto ld_a = [&](FragA& f, const char* Xc, int off) {          // off = (tap offset in pixels) * PITCH (+ s * 32 for the 16-channel steps of the 32 x 32 tiling)
+#pragma unroll
+        for (int tm = 0; tm < TMF; ++tm) {
+            const char* a = Xc + aoff[tm] + off;
+            f.h[tm] = *reinterpret_cast<const bf16x8*>(a);
+            if constexpr (!PLAIN) f.l[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
+        }
+    };
+    auto ld_b = [&](FragB& f, int slot) {
+#pragma unroll
+        for (int tn = 0; tn < TNF; ++tn) {
+            const char* b = Ws + slot * SLAB16;
+            f.h[tn] = *reinterpret_cast<const bf16x8*>(b + boff[tn]);
+            if constexpr (!PLAIN) f.l[tn] = *reinterpret_cast<const bf16x8*>(b + (boff[tn] ^ 32));
+        }
+    };
+    auto mma = [](const bf16x8& a, const bf16x8& b, const AccT& c) {
+        if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    };
+    auto mm = [&](const FragA& a, const FragB& b) {
         if (ABL(8)) return;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+        for (int tm = 0; tm < TMF; ++tm)
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                const char* a = Xc + aoff[tm] + tapoff + s * 32;
-                ah[tm] = *reinterpret_cast<const bf16x8*>(a);
-                if constexpr (!PLAIN) al[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
-            }
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) {
-                const char* b = Wb + boff[tn] + s * 32;
-                bh[tn] = *reinterpret_cast<const bf16x8*>(b);
-                if constexpr (!PLAIN) bl[tn] = *reinterpret_cast<const bf16x8*>(b + 2 * CK);
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) {
-                    if constexpr (!PLAIN) {
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-                    }
-                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            for (int tn = 0; tn < TNF; ++tn) {
+                if constexpr (!PLAIN) {
+                    acc[tm][tn] = mma(a.l[tm], b.h[tn], acc[tm][tn]);
+                    acc[tm][tn] = mma(a.h[tm], b.l[tn], acc[tm][tn]);
                 }
+                acc[tm][tn] = mma(a.h[tm], b.h[tn], acc[tm][tn]);
+            }
+    };
+    // a whole tap, fragments read in the step that uses them
+    auto mfma_cluster = [&](const char* Xc, int slot0, int tapoff) {
+#pragma unroll
+        for (int s = 0; s < (M16 ? 1 : KS); ++s) {
+            FragA a; FragB b;
+            ld_a(a, Xc, tapoff + s * 32);
+            ld_b(b, slot0 + s);
+            mm(a, b);
         }
     };
 
@@ -344,13 +421,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 #ifdef HD_STAMPS
     st_d = HD_STAMP();                 // per-thread items set up
 #endif
-    // ---- prologue: slice 0 and weight slab 0 staged, slab 1 in flight
-    {
+    int par = 0;                       // register path: iteration parity; slab `it` sits in ring slots KS * par ..
+    if constexpr (NTAPS == 9) {
+        // ---- prologue: slice 0 staged; LDS-DMA: slabs 0 and 1 on their way to ring slots 0 .. 2 KS - 1; register path: slab 0 staged, slabs 1 .. WD in flight
         const float* src; int Csrc;
         slice_src(0, src, Csrc);
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
-        w_load(S0{}, 0, 0);
+        if constexpr (GL) { w_glds(0, 0, 0); if constexpr (GD == 2) w_glds(0, 1, KS); }
+        else w_load(S0{}, HAll{}, k16_src(0, 0, 0), k16_src(0, 0, KS - 1));
 #ifdef HD_STAMPS
         st_issue = HD_STAMP();
         __builtin_amdgcn_s_waitcnt(0x0070);    // vmcnt(0) (gfx9 encoding: lgkmcnt / expcnt untouched): how long do the first loads take to arrive?
@@ -358,52 +437,101 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 #endif
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_stage(j, 0, Xs);
-        w_store(S0{}, 0);
-        if constexpr (WD == 3) {          // slabs 1, 2, 3 (a 3x3 filter has nine per slice)
-            w_load(S1{}, 0, 1); w_load(S2{}, 0, 2); w_load(S0{}, 0, 3);
-        } else if constexpr (NTAPS == 9) {
-            w_load(S0{}, 0, 1);
-        } else if (nit > 1) {
-            if (ntaps > 1) w_load(S0{}, 0, 1); else w_load(S0{}, 1, 0);
+        if constexpr (GL) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of slabs 0 and 1 have landed (the first tap's barrier publishes them)
+        } else {
+            w_store(S0{}, HAll{}, 0, 1);
+            if constexpr (WD == 3) { w_load(S1{}, HAll{}, k16_src(0, 1, 0), k16_src(0, 1, KS - 1)); w_load(S2{}, HAll{}, k16_src(0, 2, 0), k16_src(0, 2, KS - 1)); w_load(S0{}, HAll{}, k16_src(0, 3, 0), k16_src(0, 3, KS - 1)); }
+            else w_load(S0{}, HAll{}, k16_src(0, 1, 0), k16_src(0, 1, KS - 1));
+        }
+    } else {
+        // ---- prologue (any filter): slice 0 and slab 0 staged, slab 1 in flight
+        const float* src; int Csrc;
+        slice_src(0, src, Csrc);
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
+        w_load(S0{}, HAll{}, k16_src(0, 0, 0), KS > 1 ? k16_src(0, 0, 1) : nullptr);
+#ifdef HD_STAMPS
+        st_issue = HD_STAMP();
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        st_arrive = HD_STAMP();
+#endif
+#pragma unroll
+        for (int j = 0; j < MAXI; ++j) x_stage(j, 0, Xs);
+        w_store(S0{}, HAll{}, 0, 1);
+        if (nit > 1) {
+            if (ntaps > 1) w_load(S0{}, HAll{}, k16_src(0, 1, 0), KS > 1 ? k16_src(0, 1, 1) : nullptr);
+            else w_load(S0{}, HAll{}, k16_src(1, 0, 0), KS > 1 ? k16_src(1, 0, 1) : nullptr);
         }
     }
 
 #ifdef HD_STAMPS
     const unsigned long long st_loop = HD_STAMP();
 #endif
-    int buf = 0;
     if constexpr (NTAPS == 9) {
         // One tap of the main loop, tap index known at compile time.  NEXT: a next slice exists (slices
         // 0 .. nchunks-2), so the tap stores/requests unconditionally; the last slice only drains its own slabs.
         auto tap_body = [&](auto tapc, auto has_next, int c, const char* Xc, char* Xn, const float* nsrc, int nCsrc) {
             constexpr int tap = decltype(tapc)::value;
             constexpr bool NEXT = decltype(has_next)::value;
-            using SN = std::integral_constant<int, (tap + 1) % WD>;
 #ifdef HD_STAMPS
             const unsigned long long b0 = HD_STAMP();
 #endif
-            __syncthreads();             // slab `it` and the window of slice c are visible; nobody still reads slab it-1
+            // slab `it` and the window of slice c are visible; nobody still reads slab it-1.  LDS-DMA path: a raw barrier -- __syncthreads() would
+            // drain the weight DMAs still in flight (hipcc puts vmcnt(0) in front of it); every wave waited for its own pieces of slab `it` at the
+            // end of the previous tap, and the "memory" clobber keeps hipcc's LDS accesses on their side of the barrier.
+            if constexpr (GL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else __syncthreads();
 #ifdef HD_STAMPS
             st_bar += HD_STAMP() - b0;
 #endif
-            // slab it+1 (set (tap+1) % WD) -> LDS, then slab it+1+WD is requested into the set just freed
-            if constexpr (NEXT || tap + 1 < 9) w_store(SN{}, buf ^ 1);
-            if constexpr (tap + 1 + WD < 9) w_load(SN{}, c, tap + 1 + WD);
-            else if constexpr (NEXT) w_load(SN{}, c + 1, tap + 1 + WD - 9);
-            if constexpr (NEXT) {
-                if constexpr (tap == 0) pt_load(c + 1);
+            if constexpr (GL && XDB && NEXT) {      // (before this tap's DMAs are issued: hipcc waits vmcnt(0) where these items' loads are used)
+                if constexpr (tap == 2) pt_store(c + 1);
 #pragma unroll
                 for (int j = 0; j < MAXI; ++j)
-                    if (j / IPT == tap) x_load(j, nsrc, nCsrc);
-                if constexpr (XDB) {
-                    if constexpr (tap == 2) pt_store(c + 1);
+                    if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
+            }
+            auto x_req = [&]() {
+                if constexpr (NEXT) {
+                    if constexpr (tap == 0) pt_load(c + 1);
 #pragma unroll
                     for (int j = 0; j < MAXI; ++j)
-                        if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
+                        if (j / IPT == tap) x_load(j, nsrc, nCsrc);
                 }
+            };
+            if constexpr (!GL || GD == 2) x_req();
+            if constexpr (GL) {
+                // slab it+GD -> the ring slots slab it-1 was read from.  The fence pins its place among this tap's register loads so that the count
+                // at the end of the tap is exact (vmcnt retires in issue order): with two slabs ahead the DMAs go last, with one they go first.
+                __builtin_amdgcn_sched_barrier(0);
+                constexpr int t2 = tap + GD;
+                const int slot = GD == 2 ? (t2 % 3) * KS : KS * (par ^ 1);
+                if constexpr (t2 < 9) w_glds(c, t2, slot);
+                else if constexpr (NEXT) w_glds(c + 1, t2 - 9, slot);
+                if constexpr (GD == 1) { __builtin_amdgcn_sched_barrier(0); x_req(); }
+            } else {
+                // slab it+1 (set (tap+1) % WD) -> the other half of the ring, then slab it+1+WD is requested into the set just freed
+                using SO = std::integral_constant<int, (tap + 1) % WD>;
+                if constexpr (NEXT || tap + 1 < 9) w_store(SO{}, HAll{}, KS * (par ^ 1), KS * (par ^ 1) + 1);
+                constexpr int tl = tap + 1 + WD;
+                if constexpr (tl < 9) w_load(SO{}, HAll{}, k16_src(c, tl, 0), k16_src(c, tl, KS - 1));
+                else if constexpr (NEXT) w_load(SO{}, HAll{}, k16_src(c + 1, tl - 9, 0), k16_src(c + 1, tl - 9, KS - 1));
             }
-            mfma_cluster(Xc, Ws + buf * SLAB, ((tap / 3) * p.LW + tap % 3) * PITCH);
-            buf ^= 1;
+            if constexpr (!GL && XDB && NEXT) {
+                if constexpr (tap == 2) pt_store(c + 1);
+#pragma unroll
+                for (int j = 0; j < MAXI; ++j)
+                    if (j / IPT + XLAT == tap || (tap == 8 && j / IPT + XLAT > 8)) x_stage(j, c + 1, Xn);
+            }
+            mfma_cluster(Xc, GL && GD == 2 ? (tap % 3) * KS : KS * par, ((tap / 3) * p.LW + tap % 3) * PITCH);
+            if constexpr (GL) {
+                // slab it+1 (requested during tap it-1) must have landed before the next barrier.  Younger than it in the queue: this tap's register
+                // loads (two per requested item, the parameter-table vectors at tap 0) and this tap's DMAs; everything older retires first.
+                constexpr int nx = NEXT ? 2 * ((tap + 1) * IPT < MAXI ? IPT : (tap * IPT < MAXI ? MAXI - tap * IPT : 0)) + (tap == 0 ? NV : 0) : 0;
+                constexpr int ng = GD == 2 && (NEXT || tap + 2 < 9) ? NW : 0;
+                if constexpr (NEXT || tap + 1 < 9) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(nx + ng) : "memory");
+            }
+            par ^= 1;
         };
 #define HD_NINE_TAPS(NEXT_T, ...)                                                                          \
         tap_body(std::integral_constant<int, 0>{}, NEXT_T{}, __VA_ARGS__); tap_body(std::integral_constant<int, 1>{}, NEXT_T{}, __VA_ARGS__); \
@@ -433,33 +561,36 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     } else {
         // ---- any filter shape: taps in a loop; tap 0 (which requests the whole next slice) and the last slice
         // are peeled.  Slab indices past the end are clamped instead of branched around (a redundant load / a
-        // store to the idle buffer).
+        // store to the idle slots).  Slab L (all its k16 steps) lives in ring slots KS * (L & 1) ..
         int it = 0;
-        auto w_next = [&](int k) { const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps; w_load(S0{}, c, kk - c * ntaps); };
+        auto w_next = [&](int k) {
+            const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps, tp = kk - c * ntaps;
+            w_load(S0{}, HAll{}, k16_src(c, tp, 0), KS > 1 ? k16_src(c, tp, 1) : nullptr);
+        };
         auto slice = [&](int c, auto has_next) {
             constexpr bool NEXT = decltype(has_next)::value;
             const float* nsrc = nullptr; int nCsrc = 0;
             if constexpr (NEXT) slice_src(c + 1, nsrc, nCsrc);
             {
                 __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
-                w_store(S0{}, buf ^ 1);
+                w_store(S0{}, HAll{}, KS * (par ^ 1), KS * (par ^ 1) + 1);
                 w_next(it + 2);
                 if constexpr (NEXT) {
                     pt_load(c + 1);
 #pragma unroll
                     for (int j = 0; j < MAXI; ++j) x_load(j, nsrc, nCsrc);
                 }
-                mfma_cluster(Xs, Ws + buf * SLAB, 0);
-                buf ^= 1; ++it;
+                mfma_cluster(Xs, KS * par, 0);
+                par ^= 1; ++it;
             }
             int ky = 0, kx = 1;
             if (kx == p.KW) { kx = 0; ky = 1; }
             for (int tap = 1; tap < ntaps; ++tap, ++it) {
                 __syncthreads();
-                w_store(S0{}, buf ^ 1);
+                w_store(S0{}, HAll{}, KS * (par ^ 1), KS * (par ^ 1) + 1);
                 w_next(it + 2);
-                mfma_cluster(Xs, Ws + buf * SLAB, (ky * p.LW + kx) * PITCH);
-                buf ^= 1;
+                mfma_cluster(Xs, KS * par, (ky * p.LW + kx) * PITCH);
+                par ^= 1;
                 if (++kx == p.KW) { kx = 0; ++ky; }
             }
             if constexpr (NEXT) {
@@ -472,13 +603,13 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         for (int c = 0; c + 1 < nchunks; ++c) slice(c, std::true_type{});
         slice(nchunks - 1, std::false_type{});
     }
-    (void)w1; (void)w2; (void)w3; (void)v0; (void)v1; (void)v2; (void)v3; (void)u0; (void)u1; (void)u2; (void)u3; (void)pr1; (void)pr2;
+    (void)w1; (void)w2; (void)w3; (void)v0; (void)v1; (void)v2; (void)v3; (void)u0; (void)u1; (void)u2; (void)u3; (void)pr1; (void)pr2; (void)wv; (void)wdst;
 #undef HD_WLOAD
 #undef HD_WSTORE
 #ifdef HD_STAMPS
     const unsigned long long st_epi = HD_STAMP();
 #endif
-    conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(ptab));
+    conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
 #ifdef HD_STAMPS
     if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
         unsigned hwid;
@@ -495,7 +626,7 @@ template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 // (16-channel slices with the 256 x 64 tile: ~40 KB of LDS, so a third workgroup fits a CU if the registers allow -- at most 168.  The same cap on
 // the 128 x 128 variants with 16-channel slices everywhere measured a loss: 14.1 vs 13.45 ms per unet64 step.)
 // Only the plain loader fits 168 registers without scratch (the GroupNorm-apply loaders need 196: capped, they spill 12 registers -- tests/test_isa_guards.py).
-__global__ __launch_bounds__(64 * WM * WN, (CK == 16 && WM == 4 && WN == 1 && MODE == IN_NONE) ? 3 : 1) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE>() ? 3 : (NTAPS == 0 && MAXI > 4) ? 1 : 2)) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, false>(p);
 }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>

@@ -4,6 +4,18 @@
 #pragma once
 #include "hd_common.h"
 
+#ifndef HD_CONV_GLDS
+#define HD_CONV_GLDS 1    // bf16x3 3x3 kernels: weights by LDS-DMA (global_load_lds_dwordx4) into a ring of three slabs; 0: through prefetch registers +
+                          // ds_write_b128 into two (the round-2 path; A/B builds: make TAG=_g0 EXTRA=-DHD_CONV_GLDS=0).  The host's LDS plan follows it.
+#endif
+
+#ifndef HD_GLDS_D
+#define HD_GLDS_D 1       // LDS-DMA path: slabs requested ahead of the one being read (ring = HD_GLDS_D + 1 slabs); 1 and 2 measure the same (profiles/r03_*), 1 needs a third less LDS
+#endif
+#ifndef HD_MFMA16
+#define HD_MFMA16 1       // bf16x3 kernels with 32-channel slices: v_mfma_f32_16x16x32_bf16 instead of 32x32x16 (same flops per cycle; the chip holds a higher clock on it)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -24,6 +36,7 @@ struct ConvKArgs {
     float* out; float* gn_part; int gn_slots;
     int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
+    int m16;      // bf16x3 kernel family: 1 = the launch runs on 16 x 16 MFMA tiles (row -> pixel maps are laid out for 16-row operand blocks)
     int plain;    // bf16x3 kernel family: 1 = one bf16 MFMA per product (training's optional bf16 arithmetic; 8-wave 3x3 variant only)
 #ifdef HD_STAMPS
     unsigned long long* stamps;   // timing study builds only (make EXTRA=-DHD_STAMPS): [4096][16] cycle stamps, see conv_bf16x3_kernel.h
@@ -81,7 +94,13 @@ __device__ __forceinline__ void decode_row(const ConvKArgs& p, int thw, int m, i
     // one such pair: block 0 of an image = rows {0, 4} | {2, 6}, block 1 = rows {1, 5} | {3, 7}.  (Round 1 paired rows g, g + 4
     // over 16 CONSECUTIVE lanes, which the real lane groups cut across: the SQ counters showed a quarter of these layers' LDS
     // cycles as bank conflicts.)
-    if (p.TW == 8 && p.TH == 8 && p.LW == 10 && p.stride == 1) {
+    if (p.TW == 8 && p.TH == 8 && p.LW == 10 && p.stride == 1 && p.m16) {
+        // 16 x 16 MFMA tiles: an operand block is 16 GEMM rows = pixel rows j and j + 4 (10 * 4 = 8 mod 16: the block's 16 staged indices are
+        // consecutive modulo 16, which is what the 160-byte pitch of that path needs -- conv_bf16x3_kernel.h)
+        const int j = r >> 4, l = r & 15;
+        ty = j + 4 * (l >> 3);
+        tx = l & 7;
+    } else if (p.TW == 8 && p.TH == 8 && p.LW == 10 && p.stride == 1) {
         const int blk = r >> 5, l = r & 31;
         const bool inA = l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28);
         const int k = inA ? (l < 4 ? l : l < 16 ? l - 8 : l - 12) : (l < 12 ? l - 4 : l < 20 ? l - 8 : l - 16);   // position inside its group
@@ -122,7 +141,14 @@ __device__ __forceinline__ void init_tables(const ConvKArgs& p, const TileCtx& t
     }
 }
 
-// staged-pixel offset of GEMM row (wm, tm, lane) inside the LDS window
+// staged-pixel offset of GEMM row m inside the LDS window
+__device__ __forceinline__ int row_px_offset_m(const ConvKArgs& p, const TileCtx& t, int m) {
+    if (m >= t.mvalid) m = 0;
+    int tb, ty, tx;
+    decode_row(p, t.thw, m, tb, ty, tx);
+    return (tb * p.LH + ty * p.stride) * p.LW + tx * p.stride;
+}
+// ... of GEMM row (wm, tm, lane) of the 32 x 32 tiling
 template <int TM>
 __device__ __forceinline__ int row_px_offset(const ConvKArgs& p, const TileCtx& t, int tm) {
     int m = t.wm * 32 * TM + tm * 32 + t.l31;
@@ -159,9 +185,11 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 //   stage: LDS, BM x (BN + 4) floats, overlays the operand buffers (all MFMA reads are done).
 //   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
 //   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
-template <int BM, int BN, int TM, int TN, int NT>
-__device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, f32x16 (&acc)[TM][TN], const int* rowpix,
+// Acc: f32x16[TM][TN] (32 x 32 MFMA tiles) or f32x4[2 TM][2 TN] (16 x 16 tiles: col = lane & 15, row = 4 * (lane >> 4) + reg).
+template <int BM, int BN, int TM, int TN, int NT, typename Acc>
+__device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, Acc& acc, const int* rowpix,
                                               const int* rowb, float* stage) {
+    constexpr bool M16 = sizeof(acc[0][0]) == 16;
     // The tile is staged in TM rounds of BM/TM rows (round tm holds, for every wave-row wm, its rows
     // tm*32..tm*32+31), so the staging area is BM/TM x (BN+4) floats and does not set the LDS footprint.
     constexpr int EP = BN + 4, CQ = BN / 4, RPP = NT / CQ, RB = BM / TM, NPASS = RB / RPP, WMN = BM / (32 * TM);
@@ -195,13 +223,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
 #ifdef HD_STAMPS
         e1 = __builtin_readcyclecounter(); e_bar += e1 - e0;
 #endif
+        if constexpr (M16) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int col = t.wn * 32 * TN + tn * 32 + t.l31;
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = t.wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;    // row inside this round
-                stage[lr * EP + col] = acc[tm][tn][r];
+                for (int j = 0; j < 2 * TN; ++j) {
+                    const int col = t.wn * 32 * TN + j * 16 + (t.lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int lr = t.wm * 32 + ii * 16 + 4 * (t.lane >> 4) + r;    // row inside this round
+                        stage[lr * EP + col] = acc[2 * tm + ii][j][r];
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const int col = t.wn * 32 * TN + tn * 32 + t.l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = t.wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.half;    // row inside this round
+                    stage[lr * EP + col] = acc[tm][tn][r];
+                }
             }
         }
 #ifdef HD_STAMPS

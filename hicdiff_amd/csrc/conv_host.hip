@@ -117,7 +117,7 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
 
 // LDS plan of one launch: tile geometry under a per-workgroup LDS budget that keeps two workgroups
 // resident per CU (160 KiB LDS), and inside the register-prefetch capacity of the kernel variant.
-static const size_t LDS_BUDGET = 78 * 1024;
+static const size_t LDS_BUDGET = 80 * 1024;        // exactly half of a CU's 160 KiB
 static const size_t LDS_BUDGET_8W = 150 * 1024;   // 8-wave workgroups run one per CU
 struct ConvPlan { TileGeom g; bool fast; int ck, BM, BN, WM, cfg, xs_stride, pt_n4; size_t pitch, lds; };
 
@@ -145,8 +145,9 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     int nthreads = 256;
     static const int cfg3_min_hw = getenv("HICDIFF_CFG3_MINHW") ? atoi(getenv("HICDIFF_CFG3_MINHW")) : 1024;   // measured on unet64 B=256: 4096 -> 16.07, 1024 -> 15.84, 256 -> 15.78 ms/step (but a loss at 64 tiles of 40x40), 64 -> 25.8
     if (pl.fast && wide && big && taps9 && a.H * a.W >= cfg3_min_hw) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
-    pl.pitch = pl.fast ? (size_t)4 * pl.ck + 16 : (size_t)17 * 4;
-    const size_t wbytes = pl.fast ? (size_t)2 * pl.BN * pl.pitch : (size_t)2 * 16 * pl.BN * 4;
+    pl.pitch = pl.fast ? (pl.ck == 32 && taps9 && HD_MFMA16 ? (size_t)160 : (size_t)4 * pl.ck + 16) : (size_t)17 * 4;   // bf16x3: see the kernel header (16 x 16 tiles want 160)
+    // bf16x3: ring of unpadded k16-slabs of BN x 64 bytes, two taps' worth, three for the 3x3 kernels' LDS-DMA path (conv_bf16x3_kernel.h)
+    const size_t wbytes = pl.fast ? (size_t)((taps9 && HD_CONV_GLDS) ? (pl.ck == 16 ? 3 : HD_GLDS_D + 1) : 2) * (pl.ck / 16) * pl.BN * 64 : (size_t)2 * 16 * pl.BN * 4;
     const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
     // bf16x3: one sink row per window; the 8-wave variant double-buffers the window; loader-parameter table
     // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest possible)
@@ -165,7 +166,9 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     pl.xs_stride = nxb == 2 ? (int)xwin : 0;
     pl.pt_n4 = nv ? (ln ? 1 : pl.g.TB) * pl.ck / 4 : 0;
     const size_t ptbytes = (size_t)2 * nv * (pl.pt_n4 + 1) * 16;
-    pl.lds = (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(ptbytes + wbytes + nxb * xwin, stage);
+    // (bf16x3 layout: [row tables][ring][pixel tables][parameter table][windows], the epilogue's staging area overlays everything after the row tables)
+    pl.lds = pl.fast ? (size_t)2 * pl.BM * 4 + std::max((size_t)2 * npx4 * 4 + ptbytes + wbytes + nxb * xwin, stage)
+                     : (size_t)(2 * npx4 + 2 * pl.BM) * 4 + std::max(ptbytes + wbytes + nxb * xwin, stage);
     return pl;
 }
 
@@ -285,6 +288,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.out = a.out;
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     k.plain = a.plain_bf16;
+    k.m16 = 0;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
 #ifdef HD_STAMPS
@@ -326,6 +330,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     if (a.gn_part && gn_in_epilogue(pl)) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
     L.lds = pl.lds; L.ck = pl.ck; L.cfg = pl.cfg;
+    k.m16 = pl.fast && pl.pitch == 160;
     k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
     if (pl.fast && pl.pt_n4 > 256) { hd_set_error("conv: loader-parameter table needs more than 256 entries per vector"); return -1; }
     if (L.lds > 160 * 1024) { hd_set_error("conv tile needs more than 160 KiB of LDS"); return -1; }
@@ -386,7 +391,8 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
     }
 }
 
-// packed fp32 [taps][Cin][CoutPad] -> split bf16 [taps][Cin/CK][CoutPad][CK hi | CK lo]
+// packed fp32 [taps][Cin][CoutPad] -> split bf16 [taps][Cin/CK][CoutPad][CK hi | CK lo].  The bf16x3 convolution kernels read CK = 16
+// images only (their weights travel in 16-channel k-steps whatever the activation slice is); CK = 32 serves the training side's GEMMs.
 __global__ __launch_bounds__(256) void split_conv_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int taps,
                                                          int Cin, int CoutPad, int CK) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

@@ -176,22 +176,8 @@ struct Loader {
             c->owned.push_back(p);
             w->wsplit = (unsigned short*)p;
         }
-        {   // 3x3 layers with at most 64 output channels also get an image with 16-channel slices: on maps of >= 4096 pixels their 256 x 64 tile
-            // then needs ~40 KB of LDS and (registers capped at 168, conv_bf16x3_kernel.h) a third workgroup fits a CU -- 271 -> 258 us on the
-            // dominant unet64 kernel; with the plain-loader layers only (the others would spill) 13.59 -> 13.50 ms per step on one box; smaller
-            // maps keep 32 (unet40: 3.07 vs 3.09 ms).  pick_slices() chooses per launch, by the loader and the map size only.  HICDIFF_CK16_NARROW=0 turns the second image off.
-            static const bool ck16n = !(getenv("HICDIFF_CK16_NARROW") && atoi(getenv("HICDIFF_CK16_NARROW")) == 0);
-            if (ck16n && KH == 3 && !unshuffle && w->CoutPad == 64 && w->ck == 32) {   // (the 1x1 shortcuts of those layers: no change, 13.43 vs 13.42 ms)
-                if (!w->wsplit16) {
-                    void* p = nullptr;
-                    if (hipMalloc(&p, (size_t)KH * KH * cin * w->CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
-                    c->owned.push_back(p);
-                    w->wsplit16 = (unsigned short*)p;
-                }
-                HD_TRY(launch_split_conv(w->w, w->wsplit16, KH * KH, cin, w->CoutPad, 16, st));
-            }
-        }
-        HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, w->ck, st));
+        // the split image is packed in 16-channel k-steps whatever the kernel's activation slice (w->ck) is: conv_bf16x3_kernel.h
+        HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, 16, st));
         // Winograd image of the 3x3 filters (conv_winograd.hip): only while that opt-in path is switched on (HICDIFF_WINOGRAD=1 / hd_debug_winograd(1)
         // before the weights are loaded) -- the image is 16/9 of the filter bytes twice over and one more pack launch per layer; without it
         // conv_uses_winograd() is false and the layer takes the implicit-GEMM kernel
@@ -252,7 +238,7 @@ static int load_attn(Loader& L, const std::string& p, int dim, bool linear, Attn
         if (!q.w) { q.w = L.dev((size_t)dim * 128); if (!q.w) return HD_EHIP; }
         HD_TRY(launch_pack_conv((const float*)t->data, q.w, 128, dim, 1, 1, 128, 0, 0, L.st));
         if (!q.wsplit) { q.wsplit = (unsigned short*)L.dev((size_t)dim * 128); if (!q.wsplit) return HD_EHIP; }   // 2 shorts per weight
-        HD_TRY(launch_split_conv(q.w, q.wsplit, 1, dim, 128, q.ck, L.st));
+        HD_TRY(launch_split_conv(q.w, q.wsplit, 1, dim, 128, 16, L.st));
         if (!a->wkv) { a->wkv = (unsigned short*)L.dev((size_t)256 * dim); if (!a->wkv) return HD_EHIP; }
         HD_TRY(launch_pack_kv((const float*)t->data, a->norm_g, dim, a->wkv, L.st));
         if (dim == 64) {
@@ -391,10 +377,14 @@ static int probe(Run& r, const std::string& label, const Act& a) {
     return 0;
 }
 
-// the 16-channel-slice image of a layer that has one, on large maps with the plain loader (a rule by the layer, its loader and the map size only)
+// Activation slice of a launch.  3x3 layers with at most 64 output channels take 16-channel slices on maps of >= 4096 pixels when their
+// loader is the plain one: their 256 x 64 tile then needs ~40 KB of LDS and (registers capped at 168, conv_bf16x3_kernel.h) a third
+// workgroup fits a CU -- 271 -> 258 us on the dominant unet64 kernel in round 2; the transforming loaders need more registers than three
+// workgroups per CU leave, and smaller maps keep 32 (unet40: 3.07 vs 3.09 ms).  A rule by the layer, its loader and the map size only.
+// HICDIFF_CK16_NARROW=0 turns it off.
 static void pick_slices(ConvArgs& a) {
-    if (a.cw.wsplit16 && a.H * a.W >= 4096 && a.in_mode == IN_NONE) { a.cw.wsplit = a.cw.wsplit16; a.cw.ck = 16; }   // (the transforming loaders need more registers than three workgroups per CU leave)
-    a.cw.wsplit16 = nullptr;
+    static const bool ck16n = !(getenv("HICDIFF_CK16_NARROW") && atoi(getenv("HICDIFF_CK16_NARROW")) == 0);
+    if (ck16n && a.cw.KH == 3 && a.cw.KW == 3 && a.cw.CoutPad == 64 && a.cw.ck == 32 && a.H * a.W >= 4096 && a.in_mode == IN_NONE) a.cw.ck = 16;
 }
 
 static int run_conv(Run& r, ConvArgs& a) {
@@ -1094,7 +1084,7 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
     }
     if ((mode & 32) && rc == 0) {
         if (hipMalloc(&psplit, (size_t)KH * KH * Cin * cw.CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
-        rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, cw.ck, st);
+        rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, 16, st);
         a.cw.wsplit = (unsigned short*)psplit; a.cw.ck = cw.ck; a.precision = HD_PREC_BF16X3;
     }
     void* pwino = nullptr;

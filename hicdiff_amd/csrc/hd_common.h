@@ -17,11 +17,10 @@ struct Act {
 // filled), bias [Cout].  UNet 3x3 convs are weight-standardised at pack time.
 struct ConvW {
     float* w = nullptr;
-    unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/ck][CoutPad][ck hi | ck lo] (fast path)
-    unsigned short* wsplit16 = nullptr; // optional second split image with 16-channel slices, taken on feature maps of >= 4096 pixels (engine.hip pick_slices)
+    unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/16][CoutPad][16 hi | 16 lo] (fast path; always 16-channel k-steps)
     unsigned short* wino = nullptr;     // 3x3 only: Winograd F(2x2,3x3) filter transform, split bf16, MFMA-fragment order (conv_winograd.hip)
     float* bias = nullptr;
-    int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;
+    int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;   // ck: activation slice of the bf16x3 kernel (32 where the channel counts allow)
 };
 
 enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };

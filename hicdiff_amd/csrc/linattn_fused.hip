@@ -228,8 +228,9 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
 // ---- q side: the context folded into to_out ----------------------------------------------------------------
 // out[n][h*32+e] = scale * sum_d ctx[h][d][e] * softmax_d(q)[n][h*32+d] followed by the 1x1 to_out convolution is one
 // 1x1 convolution of softmax_d(q) with the per-sample weight  W'_b[o][h*32+d] = scale * sum_e Wout[o][h*32+e] * ctx_b[h][d][e]
-// (src/hicdiff.py:217-226).  This kernel writes W'_b in the split-bf16 slab layout of the conv kernel
-// ([slice = head][CoutPad][32 hi | 32 lo]); the conv's loader then applies the softmax (IN_SOFTMAX32).
+// (src/hicdiff.py:217-226).  This kernel writes W'_b in the split-bf16 image layout of the conv kernel
+// ([16-channel k-step = 2 * head + d / 16][CoutPad][16 hi | 16 lo]); the conv's loader then applies the softmax (IN_SOFTMAX32).
+// permute != 0: the chained q kernel's own layout instead ([head][CoutPad][32 hi | 32 lo], d in accumulator order).
 __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __restrict__ wout, const float* __restrict__ ctx, int CoutPad,
                                                                unsigned short* __restrict__ dst, int permute) {
     constexpr int D = 32;
@@ -249,9 +250,15 @@ __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __re
         const __bf16 lo = (__bf16)(acc - (float)hi);
         // permute: d axis in the order an MFMA accumulator presents it as an operand (linattn_q_fused.hip):
         // position 16*s + 8*half + 4*g + i  <-  d = 16*s + 8*g + 4*half + i
-        const int pos = permute ? (d & 16) | ((d & 4) << 1) | ((d & 8) >> 1) | (d & 3) : d;
-        out[(size_t)o * 2 * D + pos] = __builtin_bit_cast(unsigned short, hi);
-        out[(size_t)o * 2 * D + D + pos] = __builtin_bit_cast(unsigned short, lo);
+        if (permute) {
+            const int pos = (d & 16) | ((d & 4) << 1) | ((d & 8) >> 1) | (d & 3);
+            out[(size_t)o * 2 * D + pos] = __builtin_bit_cast(unsigned short, hi);
+            out[(size_t)o * 2 * D + D + pos] = __builtin_bit_cast(unsigned short, lo);
+        } else {
+            unsigned short* row = out + ((size_t)(d >> 4) * CoutPad + o) * 32;
+            row[d & 15] = __builtin_bit_cast(unsigned short, hi);
+            row[16 + (d & 15)] = __builtin_bit_cast(unsigned short, lo);
+        }
     }
 }
 

@@ -1512,16 +1512,16 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     for (int i = 0; i <= n; ++i) {
         const float* w = params + tr->o_conv_w[i];
         TR_TRY(launch_pack_conv(w, tr->fwd[i].w, F, F, 3, 3, F, 0, 0, st));
-        TR_TRY(launch_split_conv(tr->fwd[i].w, tr->fwd[i].wsplit, 9, F, F, 32, st));
+        TR_TRY(launch_split_conv(tr->fwd[i].w, tr->fwd[i].wsplit, 9, F, F, 16, st));
         tr->fwd[i].bias = const_cast<float*>(params + tr->o_conv_b[i]);
         hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)(((size_t)9 * F * F + 255) / 256)), dim3(256), 0, st, w, F, F, tr->wt_tmp);
         TR_TRY(check_launch("flip_weight"));
         TR_TRY(launch_pack_conv(tr->wt_tmp, tr->bwd[i].w, F, F, 3, 3, F, 0, 0, st));
-        TR_TRY(launch_split_conv(tr->bwd[i].w, tr->bwd[i].wsplit, 9, F, F, 32, st));
+        TR_TRY(launch_split_conv(tr->bwd[i].w, tr->bwd[i].wsplit, 9, F, F, 16, st));
         tr->bwd[i].bias = nullptr;
     }
     TR_TRY(launch_pack_conv(params + tr->o_tail_w, tr->tail_fwd.w, 1, F, 3, 3, 64, 0, 0, st));
-    TR_TRY(launch_split_conv(tr->tail_fwd.w, tr->tail_fwd.wsplit, 9, F, 64, 32, st));
+    TR_TRY(launch_split_conv(tr->tail_fwd.w, tr->tail_fwd.wsplit, 9, F, 64, 16, st));
     tr->tail_fwd.bias = const_cast<float*>(params + tr->o_tail_b);
     hipLaunchKernelGGL(flip_weight_kernel, dim3((9 * F + 255) / 256), dim3(256), 0, st, params + tr->o_tail_w, 1, F, tr->tail_flip);   // -> [F][1][3][3]
     TR_TRY(check_launch("flip_tail"));
