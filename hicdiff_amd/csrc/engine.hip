@@ -120,7 +120,7 @@ struct hd_ctx {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     StepParams* sp_dev = nullptr;
-    bool use_graphs = true;
+    int use_graphs = -1;           // 1 / 0: always / never replay the fused steps from a hipGraph; -1 (default): by the amount of work, see run_step
     // test-only capture of intermediates (hicdiff_hip_debug.h)
     bool capture = false;
     std::unordered_map<std::string, Act> captured;
@@ -351,16 +351,17 @@ static int load_hicedrn(Loader& L) {
 // ---- forward plans -----------------------------------------------------------------------------
 struct Run {
     hd_ctx* c; hipStream_t st; bool dry;
+    Pool* pool;
     int B, S;
     // time embedding rows: Bt == B (per-sample t) or 1 (every tile at the same step)
     int Bt; const float* film; int film_bs;
     int alloc(size_t n, float** p) {
-        if (!c->pool.alloc(n * sizeof(float), p)) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) with the batch and tile size first");
+        if (!pool->alloc(n * sizeof(float), p)) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) with the batch and tile size first");
         return 0;
     }
     int act(int H, int W, int C, Act* a) { a->B = B; a->H = H; a->W = W; a->C = C; return alloc(a->numel(), &a->p); }
-    void free(float* p) { c->pool.release(p); }
-    void free(Act& a) { c->pool.release(a.p); a.p = nullptr; }
+    void free(float* p) { pool->release(p); }
+    void free(Act& a) { pool->release(a.p); a.p = nullptr; }
 };
 
 static int probe(Run& r, const std::string& label, const Act& a) {
@@ -570,9 +571,13 @@ static int time_and_film(Run& r, const void* t, int t_kind, float tval, bool uni
     HD_TRY(r.alloc((size_t)r.Bt * c->time_dim, &tact));
     HD_TRY(r.alloc((size_t)r.Bt * c->film_n, &film));
     if (!r.dry) {
-        HD_TRY(launch_time_mlp(uniform ? nullptr : t, t_kind, tval, sp, c->arch.sr3, r.Bt, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t,
-                               c->b3, temb, tact, r.st));
-        HD_TRY(launch_film(tact, r.Bt, c->time_dim, c->film_wt, c->film_b, c->film_n, film, r.st));
+        if (uniform && c->precision == HD_PREC_BF16X3 && c->time_dim % 256 == 0 && c->time_dim <= 1024 && c->time_in <= 256 && c->time_in % 16 == 0 && c->film_n % 4 == 0) {   // one time row: MLP + every FiLM projection in one launch (the exact-fp32 mode keeps the two kernels whose summation order its parity margins were measured with: DDIM amplifies 1e-7 to 1e-3)
+            HD_TRY(launch_time_film(tval, sp, c->arch.sr3, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t, c->b3, c->film_wt, c->film_b, c->film_n, film, r.st));
+        } else {
+            HD_TRY(launch_time_mlp(uniform ? nullptr : t, t_kind, tval, sp, c->arch.sr3, r.Bt, c->time_in, c->time_dim, c->w1t, c->b1, c->w3t,
+                                   c->b3, temb, tact, r.st));
+            HD_TRY(launch_film(tact, r.Bt, c->time_dim, c->film_wt, c->film_b, c->film_n, film, r.st));
+        }
     }
     r.free(temb); r.free(tact);
     r.film = film; r.film_bs = uniform ? 0 : c->film_n;
@@ -693,7 +698,7 @@ static int hicedrn_forward(Run& r, const float* x, const float* cond, float* eps
 }
 
 static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float tval, bool uniform, const float* cond, float* eps,
-                   int B, int S, hipStream_t st, bool dry, const StepParams* sp = nullptr) {
+                   int B, int S, hipStream_t st, bool dry, const StepParams* sp = nullptr, Pool* pool = nullptr) {
     if (B < 1 || S < 8) return fail(c, HD_EINVAL, "bad batch or tile size");
     if (c->arch.kind == HD_ARCH_UNET) {
         int div = 1; for (int i = 0; i + 1 < c->arch.n_mults; ++i) div *= 2;
@@ -702,8 +707,9 @@ static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float t
     if ((S * S) % 4) return fail(c, HD_EINVAL, "S*S must be a multiple of 4");
     if (!dry && !c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
     if (!dry && (c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
-    Run r{c, st, dry, B, S, B, nullptr, 0};
-    c->pool.reset(dry);
+    if (!pool) pool = &c->pool;
+    Run r{c, st, dry, pool, B, S, B, nullptr, 0};
+    pool->reset(dry);
     float* film = nullptr;
     HD_TRY(time_and_film(r, t, t_kind, tval, uniform, sp, &film));
     int rc = c->arch.kind == HD_ARCH_UNET ? unet_forward(r, x, cond, eps) : hicedrn_forward(r, x, cond, eps);
@@ -754,7 +760,7 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->time_in = a->dim; c->time_dim = a->dim * 4;
     c->ck = (a->dim % 32 == 0) ? 32 : 16;
     if (const char* k = getenv("HICDIFF_CK")) { if (atoi(k) == 16) c->ck = 16; }   // tuning experiments
-    if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0;
+    if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0 ? 1 : 0;
     if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
     else { c->first_ks = 3; c->first_cout = a->dim; c->film_n = a->number_resnet * (a->sr3 ? 1 : 2) * a->dim; }
@@ -845,8 +851,12 @@ static int step_body(hd_ctx* c, int kind, float* x, const float* aux, const floa
 static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float* noise, const StepParams& v, float* x0_out, int B,
                     int S, hipStream_t user) {
     if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
-    // Replayed noise changes address every step and event profiling records per launch: both run eagerly.
-    if (!c->use_graphs || noise != nullptr || hd_prof_is_on() || c->capture) return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
+    // Replayed noise changes address every step and event profiling records per launch: both run eagerly.  So do small batches unless graphs are
+    // forced on: below ~256 k pixels per step the kernels are latency-bound and the eager launches of an idle host thread ran 6-10 % faster than
+    // the replay (unet40: 4 tiles 2.23 vs 2.46 ms per step, 64 tiles 2.89 vs 3.08; profiles/r03_f_*), at full batches the two measure the same
+    // (unet64, 256 tiles: 13.0-13.2 ms either way) and the replay keeps the step independent of what the host thread is doing.
+    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= 262144;
+    if (!graphs || noise != nullptr || hd_prof_is_on() || c->capture) return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
     if (!c->gstream) {
         if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&c->sp_dev, sizeof(StepParams)) != hipSuccess)
@@ -915,7 +925,7 @@ int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_d
 
 int hd_set_graphs(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
-    c->use_graphs = enable != 0;
+    c->use_graphs = enable != 0 ? 1 : 0;
     return HD_OK;
 }
 

@@ -114,6 +114,9 @@ int launch_rowdot(const float* x, const float* w, const float* bias, float* out,
 int launch_time_mlp(const void* t, int t_kind, float tval, const StepParams* sp, int sr3, int Bt, int dim, int time_dim, const float* w1t,
                     const float* b1, const float* w3t, const float* b3, float* temb, float* temb_act, hipStream_t st);
 int launch_film(const float* act, int Bt, int K, const float* wt, const float* bias, int N, float* out, hipStream_t st);
+// both of the above in one launch for the sampling loops' single time row (time_dim % 256 == 0 up to 1024, dim <= 256, dim % 16 == 0, N % 4 == 0)
+int launch_time_film(float tval, const StepParams* sp, int sr3, int dim, int time_dim, const float* w1t, const float* b1, const float* w3t,
+                     const float* b3, const float* wt, const float* bias, int N, float* out, hipStream_t st);
 
 int launch_gn_partial(const float* x, int B, int HW, int C, float* part, int* slots_out, hipStream_t st);
 int launch_gn_finalize(const float* part, int slots, int B, int HW, int C, int groups, const float* gamma,
@@ -162,11 +165,11 @@ int launch_attn_full(const float* qkv, int B, int HW, int heads, float* out, hip
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1,
                        float coef2, float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off,
-                       uint32_t step, const StepParams* sp, hipStream_t st, float coef_eps = 0.f);
+                       uint32_t step, const StepParams* sp, hipStream_t st, float coef_eps = 0.f, uint32_t tile_add = 0);   // tile_add: added to sp's tile offset (chained steps)
 int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
                        float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC,
                        float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
-                       hipStream_t st);
+                       hipStream_t st, uint32_t tile_add = 0);
 int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st);
 int launch_q_sample(const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S,
                     hipStream_t st);

@@ -13,6 +13,8 @@
 // rescales and normalises them in a fixed order.
 #include "hd_common.h"
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -188,6 +190,175 @@ __global__ __launch_bounds__(256) void linattn_kv_fused_kernel(const float* __re
     }
 }
 
+// ---- 64-channel maps: the same computation with the weights RESIDENT in LDS and several 64-token chunks per workgroup --------------
+// The kernel above reloads its 64 KB weight image for every 16 KB of activations (one chunk per workgroup): at C = 64 four fifths of its
+// memory traffic are weights from L2 and every workgroup is a chain of exposed latencies (x, LayerNorm, weights, MFMA) -- 173 us per launch
+// at 256 x 64 x 64, 1.5 TB/s.  Here a workgroup loads the image once (LDS-DMA, both 32-channel slices, unpadded rows with XOR-swizzled
+// 16-byte pieces: 64 KB), then walks up to CPW chunks of its sample: the next chunk's token rows are requested while the current chunk
+// is multiplied, a chunk's two slices are staged together (two barriers per chunk), and each chunk emits the same flash-style partials
+// as before (no state is carried from chunk to chunk, so the combine kernel and every result bit stay as they were).
+// LDS: 64 KB weights + 16 KB token tiles = half a CU: two workgroups per CU.
+__global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wkv, int HW, int nsplit,
+                                                              int cpw, float* __restrict__ pmax, float* __restrict__ psum, float* __restrict__ pctx) {
+    constexpr int C = 64, CK = 32, ROWB = 4 * CK, heads = 4, D = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ws = smem;                                   // [2 slices][256 rows][128 B]
+    char* Xs = smem + 2 * 256 * ROWB;                  // [2 slices][64 tokens][128 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int groups = (nsplit + cpw - 1) / cpw;
+    const int b = blockIdx.x / groups, sp0 = (blockIdx.x % groups) * cpw, sp1 = min(nsplit, sp0 + cpw);
+
+    // weights: 64 wave-instructions of 1 KiB (8 rows each); LDS takes them linearly, so lane l (slot l & 7 of row l >> 3) fetches piece
+    // (l & 7) ^ ((row >> 1) & 7) of its row
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(w);
+        const int r8 = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int blk = i * 4 + wv;                // 1 KiB block = rows 8 blk .. 8 blk + 7 of the [512][128 B] image
+            const int row = blk * 8 + r8;
+            const char* src = reinterpret_cast<const char*>(wkv) + (size_t)row * ROWB + (((lane & 7) ^ ((row >> 1) & 7)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(Ws + blk * 1024), 16, 0, 0);
+        }
+    }
+
+    const int tok = tid >> 2, part = tid & 3;          // 4 threads per token, 16 channels each: parts 0, 1 -> slice 0, parts 2, 3 -> slice 1
+    float4 xv[4];
+    auto x_req = [&](int sp) {
+        const int n0 = sp * KV_TOK, ntok = min(KV_TOK, HW - n0);
+        const float* row = x + ((size_t)b * HW + n0 + (tok < ntok ? tok : 0)) * C + part * 16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = reinterpret_cast<const float4*>(row)[j];
+    };
+    x_req(sp0);
+    // operand addresses (swizzled): A = token rows, B = this head's 64 weight rows
+    int aoff[2], boff[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) { const int r = tm * 32 + l31; aoff[tm] = r * ROWB + ((((r >> 1) & 7) ^ half) << 4); }
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn) { const int r = w * 64 + tn * 32 + l31; boff[tn] = r * ROWB + ((((r >> 1) & 7) ^ half) << 4); }
+    const int xdst = (part >> 1) * 64 * ROWB + tok * ROWB;           // this thread's token row in its slice's tile
+    const int xsw = (tok >> 1) & 7, xp0 = (part & 1) * 2;            // its two 8-channel groups are pieces xp0, xp0 + 1 (hi) and + 4 (lo)
+
+    for (int sp = sp0; sp < sp1; ++sp) {
+        const int n0 = sp * KV_TOK, ntok = min(KV_TOK, HW - n0);
+        const bool tvalid = tok < ntok;
+        // ---- LayerNorm of the token row (in registers), split, stage
+        float s = (xv[0].x + xv[0].y + xv[0].z + xv[0].w) + (xv[1].x + xv[1].y + xv[1].z + xv[1].w) + (xv[2].x + xv[2].y + xv[2].z + xv[2].w) +
+                  (xv[3].x + xv[3].y + xv[3].z + xv[3].w);
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        const float mean = s / C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a0 = xv[j].x - mean, a1 = xv[j].y - mean, a2 = xv[j].z - mean, a3 = xv[j].w - mean;
+            q += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+        }
+        q += __shfl_xor(q, 1); q += __shfl_xor(q, 2);
+        const float rstd = 1.f / sqrtf(q / C + 1e-5f);
+        uint4 hi[2], lo[2];
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+            const float4 a = xv[2 * g8], bq = xv[2 * g8 + 1];
+            float v[8] = {(a.x - mean) * rstd, (a.y - mean) * rstd, (a.z - mean) * rstd, (a.w - mean) * rstd,
+                          (bq.x - mean) * rstd, (bq.y - mean) * rstd, (bq.z - mean) * rstd, (bq.w - mean) * rstd};
+            split8v(v, hi[g8], lo[g8]);
+            if (!tvalid) { hi[g8] = make_uint4(0, 0, 0, 0); lo[g8] = hi[g8]; }
+        }
+        if (sp + 1 < sp1) x_req(sp + 1);               // the next chunk's rows travel while this one is multiplied
+        // Raw barriers in this loop: the waves only share LDS.  __syncthreads() is also a fence for global memory -- hipcc puts vmcnt(0) in
+        // front of it, i.e. every chunk would wait for the round trip of the previous chunk's partial stores and, behind them in the queue,
+        // for the rows just requested (measured: 5.6 us per chunk instead of ~1).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the previous chunk's operand reads are done
+#pragma unroll
+        for (int g8 = 0; g8 < 2; ++g8) {
+            *reinterpret_cast<uint4*>(Xs + xdst + (((xp0 + g8) ^ xsw) << 4)) = hi[g8];
+            *reinterpret_cast<uint4*>(Xs + xdst + (((xp0 + g8 + 4) ^ xsw) << 4)) = lo[g8];
+        }
+        if (sp == sp0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first chunk: this wave's weight DMAs have landed (the barrier below publishes them)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 ah[2], al[2], bh[2], bl[2];
+                const int po = ks * 32;                // pieces 2 ks, 2 ks + 1 (hi); + 64 bytes = lo
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const char* a = Xs + sl * 64 * ROWB;
+                    ah[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm] ^ po));
+                    al[tm] = *reinterpret_cast<const bf16x8*>(a + (aoff[tm] ^ po ^ 64));
+                }
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    const char* bp = Ws + sl * 256 * ROWB;
+                    bh[tn] = *reinterpret_cast<const bf16x8*>(bp + (boff[tn] ^ po));
+                    bl[tn] = *reinterpret_cast<const bf16x8*>(bp + (boff[tn] ^ po ^ 64));
+                }
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+                    }
+            }
+
+        // ---- column softmax statistics of k over the chunk's tokens (rows = registers), p = exp(k - max)
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (t < ntok) mx = fmaxf(mx, acc[tm][0][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float ps = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float pe = t < ntok ? __expf(acc[tm][0][r] - mx) : 0.f;
+                acc[tm][0][r] = pe;
+                ps += pe;
+                if (t >= ntok) acc[tm][1][r] = 0.f;                // v of tokens past the end
+            }
+        ps += __shfl_xor(ps, 32);
+        f32x16 ctx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl, vh, vl;
+                acc_to_frag(acc[tm][0], s2, ph, pl);
+                acc_to_frag(acc[tm][1], s2, vh, vl);
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl, vh, ctx, 0, 0, 0);
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vl, ctx, 0, 0, 0);
+                ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vh, ctx, 0, 0, 0);
+            }
+        const size_t slot = ((size_t)b * heads + w) * nsplit + sp;
+        if (half == 0) { pmax[slot * D + l31] = mx; psum[slot * D + l31] = ps; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = (r & 3) + 8 * (r >> 2) + 4 * half;      // C/D layout: row = d, column (lane) = e
+            pctx[(slot * D + d) * D + l31] = ctx[r];
+        }
+    }
+}
+
 // to_qkv weight [384][C] (torch) + LayerNorm gain g[C] -> the kernel's split k/v image
 __global__ __launch_bounds__(256) void pack_kv_kernel(const float* __restrict__ wqkv, const float* __restrict__ g, int C,
                                                       unsigned short* __restrict__ dst) {
@@ -216,7 +387,22 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
                             hipStream_t st) {
     const int nsplit = linattn_kv_nsplit(HW);
     const dim3 grid((unsigned)(B * nsplit));
-    if (C == 64) hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
+    static const bool old64 = getenv("HICDIFF_KV64_OLD") && atoi(getenv("HICDIFF_KV64_OLD")) != 0;      // A/B switch of the round-3 kernel
+    if (C == 64 && !old64) {
+        static bool raised = false;
+        if (!raised) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_kv64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+                hd_set_error("linattn_kv64: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
+            }
+            raised = true;
+        }
+        // chunks per workgroup: as many as leave about two rounds of workgroups on 256 CUs x 2 slots, at most 16 (by the map size and the
+        // batch only in the grid shape -- the partials do not depend on how chunks are grouped)
+        int cpw = 16;
+        while (cpw > 1 && (long long)B * ((nsplit + cpw - 1) / cpw) < 1024) cpw >>= 1;
+        const int groups = (nsplit + cpw - 1) / cpw;
+        hipLaunchKernelGGL(linattn_kv64_kernel, dim3((unsigned)(B * groups)), dim3(256), 80 * 1024, st, x, wkv, HW, nsplit, cpw, pmax, psum, pctx);
+    } else if (C == 64) hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
     else if (C == 128) hipLaunchKernelGGL(linattn_kv_fused_kernel<128>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
     else if (C == 256) hipLaunchKernelGGL(linattn_kv_fused_kernel<256>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
     else { hd_set_error("linattn_kv_fused: 64-, 128- and 256-channel maps only"); return -1; }

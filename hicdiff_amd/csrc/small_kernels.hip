@@ -171,6 +171,81 @@ int launch_film(const float* act, int Bt, int K, const float* wt, const float* b
     return check_launch("film");
 }
 
+// The sampling loops feed every tile the same step value, so the time MLP (src/hicdiff.py:286-292; SR3 src/hicdiff_sr3.py:326-334) and all
+// FiLM projections have ONE input row per step.  One launch does both: every workgroup recomputes the 2-layer MLP (82 k MACs) and then its
+// 256 FiLM outputs.  Each dot product is cut four ways over the waves (k quarters) with float4 columns per lane, so the serial chain is
+// K/4 coalesced 16-byte loads instead of K dependent 4-byte ones (time_mlp 39 us + film 32 us -> one launch of a few us).
+__global__ __launch_bounds__(256) void time_film_kernel(float tval, const StepParams* __restrict__ sp, int sr3, int dim, int time_dim,
+                                                        const float* __restrict__ w1t, const float* __restrict__ b1, const float* __restrict__ w3t,
+                                                        const float* __restrict__ b3, const float* __restrict__ wt, const float* __restrict__ bias, int N,
+                                                        float* __restrict__ out) {
+    __shared__ float emb[256], h1[1024], act[1024];
+    __shared__ float4 red[4][64];
+    const int tid = threadIdx.x, q = tid & 63, kg = tid >> 6;       // column quad, k quarter
+    if (sp) tval = sp->f[0];
+    const int half = dim / 2;
+    for (int i = tid; i < dim; i += 256) {
+        const int k = i < half ? i : i - half;
+        const float f = sr3 ? expf(-9.210340371976184f * ((float)k / (float)half)) : expf((float)k * -(9.210340371976184f / (float)(half - 1)));
+        const float a = tval * f;
+        emb[i] = i < half ? sinf(a) : cosf(a);
+    }
+    __syncthreads();
+    // y[4q..4q+3] = sum_k x[k] * W[k][4q..] over this wave's k quarter; W row-major [K][ld]
+    auto gemv4 = [&](const float* x, int K, const float* W, int ld, int col0, bool live) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k0 = kg * (K / 4), k1 = k0 + K / 4;
+        if (live) {
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(W + (size_t)k * ld + col0);
+                const float xv = x[k];
+                acc.x = fmaf(xv, w.x, acc.x); acc.y = fmaf(xv, w.y, acc.y); acc.z = fmaf(xv, w.z, acc.z); acc.w = fmaf(xv, w.w, acc.w);
+            }
+        }
+        red[kg][q] = acc;
+        __syncthreads();
+        float4 r = red[0][q];
+        if (kg == 0) {
+#pragma unroll
+            for (int g = 1; g < 4; ++g) { const float4 t = red[g][q]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+        }
+        __syncthreads();
+        return r;                                                   // valid in wave 0
+    };
+    for (int c0 = 0; c0 < time_dim; c0 += 256) {                    // time_dim: 256 (UNet, dim 64) or 1024 (hicedrn)
+        const float4 r = gemv4(emb, dim, w1t, time_dim, c0 + 4 * q, true);
+        if (kg == 0) {
+            const float v[4] = {r.x + b1[c0 + 4 * q], r.y + b1[c0 + 4 * q + 1], r.z + b1[c0 + 4 * q + 2], r.w + b1[c0 + 4 * q + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h1[c0 + 4 * q + j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+        }
+    }
+    __syncthreads();
+    for (int c0 = 0; c0 < time_dim; c0 += 256) {
+        const float4 r = gemv4(h1, time_dim, w3t, time_dim, c0 + 4 * q, true);
+        if (kg == 0) {
+            const float v[4] = {r.x + b3[c0 + 4 * q], r.y + b3[c0 + 4 * q + 1], r.z + b3[c0 + 4 * q + 2], r.w + b3[c0 + 4 * q + 3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) act[c0 + 4 * q + j] = sr3 ? v[j] : silu_f(v[j]);
+        }
+    }
+    __syncthreads();
+    const int n0 = blockIdx.x * 256 + 4 * q;
+    const float4 r = gemv4(act, time_dim, wt, N, n0, n0 < N);
+    if (kg == 0 && n0 < N) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n0);
+        *reinterpret_cast<float4*>(out + n0) = make_float4(r.x + bv.x, r.y + bv.y, r.z + bv.z, r.w + bv.w);
+    }
+}
+
+// uniform step value only (one time row); dim <= 256 and a multiple of 16, time_dim a multiple of 256 up to 1024, N a multiple of 4 (the caller checks)
+int launch_time_film(float tval, const StepParams* sp, int sr3, int dim, int time_dim, const float* w1t, const float* b1, const float* w3t,
+                     const float* b3, const float* wt, const float* bias, int N, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(time_film_kernel, dim3((N + 255) / 256), dim3(256), 0, st, tval, sp, sr3, dim, time_dim, w1t, b1, w3t, b3, wt, bias, N, out);
+    return check_launch("time_film");
+}
+
 // ------------------------------------------------------------------------------------------------
 // GroupNorm (nn.GroupNorm(8, C), src/hicdiff.py:159).  Statistics are kept as per-channel partial
 // (sum, sum of squares) over pixel slots -- the same format the conv epilogue emits -- and folded
@@ -639,12 +714,12 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
                                                           const float* __restrict__ noise, float c_recip, float c_recipm1,
                                                           float coef1, float coef2, float sigma, float* __restrict__ x0_out, int B,
                                                           int SS4, uint64_t seed, uint64_t tile_off, uint32_t step,
-                                                          const StepParams* __restrict__ sp, float coef_eps) {
+                                                          const StepParams* __restrict__ sp, float coef_eps, uint32_t tile_add) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)B * SS4) return;
     if (sp) {
         c_recip = sp->f[1]; c_recipm1 = sp->f[2]; coef1 = sp->f[3]; coef2 = sp->f[4]; sigma = sp->f[5]; coef_eps = sp->f[6];
-        seed = sp->seed; tile_off = sp->tile_off; step = sp->step;
+        seed = sp->seed; tile_off = sp->tile_off + tile_add; step = sp->step;      // tile_add: first tile of this launch inside the call's batch (chained steps)
     }
     const float4 xv = reinterpret_cast<float4*>(x)[i];
     const float4 ev = reinterpret_cast<const float4*>(eps)[i];
@@ -665,11 +740,11 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(float* __restrict__ x,
 
 int launch_ddpm_update(float* x, const float* eps, const float* noise, float c_recip, float c_recipm1, float coef1, float coef2,
                        float sigma, float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
-                       hipStream_t st, float coef_eps) {
+                       hipStream_t st, float coef_eps, uint32_t tile_add) {
     if ((S * S) % 4) { hd_set_error("tile size must make S*S a multiple of 4"); return -1; }
     const int SS4 = S * S / 4;
     hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)(((size_t)B * SS4 + 255) / 256)), dim3(256), 0, st, x, eps, noise, c_recip,
-                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step, sp, coef_eps);
+                       c_recipm1, coef1, coef2, sigma, x0_out, B, SS4, seed, tile_off, step, sp, coef_eps, tile_add);
     return check_launch("ddpm_update");
 }
 
@@ -680,13 +755,13 @@ __global__ __launch_bounds__(256) void ddrm_update_kernel(float* __restrict__ x,
                                                           float sqrt_1m_at, float sqrt_at_next, float sigma_next, float sigma_0,
                                                           float etaA, float etaB, float etaC, float* __restrict__ x0_out,
                                                           size_t n, int SS, uint64_t seed, uint64_t tile_off, uint32_t step,
-                                                          const StepParams* __restrict__ sp) {
+                                                          const StepParams* __restrict__ sp, uint32_t tile_add) {
     const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i4 * 4 >= n) return;
     if (sp) {
         sqrt_at = sp->f[1]; sqrt_1m_at = sp->f[2]; sqrt_at_next = sp->f[3]; sigma_next = sp->f[4]; sigma_0 = sp->f[5];
         etaA = sp->f[6]; etaB = sp->f[7]; etaC = sp->f[8];
-        seed = sp->seed; tile_off = sp->tile_off; step = sp->step;
+        seed = sp->seed; tile_off = sp->tile_off + tile_add; step = sp->step;      // tile_add: first tile of this launch inside the call's batch (chained steps)
     }
     const float4 xv = reinterpret_cast<float4*>(x)[i4];
     const float4 ev = reinterpret_cast<const float4*>(eps)[i4];
@@ -717,11 +792,11 @@ __global__ __launch_bounds__(256) void ddrm_update_kernel(float* __restrict__ x,
 
 int launch_ddrm_update(float* x, const float* eps, const float* y, const float* z, float sqrt_at, float sqrt_1m_at,
                        float sqrt_at_next, float sigma_next, float sigma_0, float etaA, float etaB, float etaC, float* x0_out, int B,
-                       int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp, hipStream_t st) {
+                       int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp, hipStream_t st, uint32_t tile_add) {
     if ((S * S) % 4) { hd_set_error("tile size must make S*S a multiple of 4"); return -1; }
     const size_t n = (size_t)B * S * S;
     hipLaunchKernelGGL(ddrm_update_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, x, eps, y, z, sqrt_at, sqrt_1m_at,
-                       sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC, x0_out, n, S * S, seed, tile_off, step, sp);
+                       sqrt_at_next, sigma_next, sigma_0, etaA, etaB, etaC, x0_out, n, S * S, seed, tile_off, step, sp, tile_add);
     return check_launch("ddrm_update");
 }
 

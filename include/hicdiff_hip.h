@@ -162,7 +162,8 @@ int hd_fwht(float* data, int N, int L, float scale, void* stream);
 /* hd_ddpm_step / hd_ddrm_step with device-generated noise replay a captured hipGraph of the whole step
  * (one per (B, S, tensor addresses); the per-step scalars travel through a 1-thread kernel) on a
  * stream owned by the context, ordered after/before the caller's stream by events.  0 disables it
- * (every kernel is then launched eagerly on the caller's stream); env HICDIFF_GRAPHS=0|1 sets the default. */
+ * (every kernel is then launched eagerly on the caller's stream), 1 forces it; untouched, a context replays steps of at least
+ * 256 k pixels (B*S*S) and launches smaller ones eagerly (measured faster there); env HICDIFF_GRAPHS=0|1 forces either at hd_create. */
 int hd_set_graphs(hd_ctx* ctx, int enable);
 
 /* ---- the hot path -------------------------------------------------------------------------- */

@@ -85,6 +85,13 @@ def precision(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(autouse=True)
+def _graphs_forced_on(monkeypatch):
+    """These tests are about the hipGraph replay of the fused steps.  Contexts replay by default only from 256 k pixels per step on (smaller
+    steps run faster eagerly: engine.hip run_step); the environment switch, read at hd_create, forces the replay for the small shapes used here."""
+    monkeypatch.setenv("HICDIFF_GRAPHS", "1")
+
+
 def _set_graphs(model, on):
     eng = model.engine(torch.device("cuda", torch.cuda.current_device()))
     assert eng.lib.hd_set_graphs(eng.ctx, 1 if on else 0) == 0
