@@ -122,8 +122,11 @@ __device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
 #ifndef HD_CK16_CAP3
 #define HD_CK16_CAP3 1    // 1: the plain-loader 256 x 64 tile with 16-channel slices is capped at 168 registers (three workgroups per CU)
 #endif
-template <int WM, int WN, int CK, int MODE>
-constexpr bool conv_cap3() { return HD_CK16_CAP3 && CK == 16 && WM == 4 && WN == 1 && MODE == IN_NONE; }
+template <int WM, int WN, int CK, int MODE, int NTAPS>
+constexpr bool conv_cap3() { return HD_CK16_CAP3 && NTAPS == 9 && CK == 16 && WM == 4 && WN == 1 && MODE == IN_NONE; }
+#ifndef HD_CONV_XD2
+#define HD_CONV_XD2 1     // any-filter kernels: two activation prefetch register sets (0: one, the round-2 form; A/B builds)
+#endif
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
 __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
@@ -340,19 +343,28 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     using S2 = std::integral_constant<int, 2>;
     using HAll = std::integral_constant<int, (1 << KS) - 1>;
 
-    float4 xr[MAXI][2];
-    auto x_load = [&](int j, const float* src, int Csrc) {       // src already points at (slice, q8)
+    // raw activation prefetch registers.  The any-filter kernels with small windows keep TWO sets (slices c+1 and c+2 in flight): with one tap
+    // per slice a set requested during slice c is consumed a single MFMA cluster later, far inside the HBM latency (the 1x1 shortcut at 64 x 64
+    // ran at 57 % of its HBM share, every slice an exposed round trip).  The set index is a compile-time constant at every use.
+    constexpr int XD = NTAPS == 0 && MAXI <= 4 && HD_CONV_XD2 ? 2 : 1;
+    float4 xr[XD][MAXI][2];
+    using X0 = std::integral_constant<int, 0>;
+    using X1 = std::integral_constant<int, XD - 1>;
+    auto x_load_s = [&](auto set, int j, const float* src, int Csrc) {       // src already points at (slice, q8)
         if (ABL(32)) return;
+        constexpr int Q = decltype(set)::value;
         const float* g = src + (size_t)it_src[j] * Csrc;
-        xr[j][0] = *reinterpret_cast<const float4*>(g);
-        xr[j][1] = *reinterpret_cast<const float4*>(g + 4);
+        xr[Q][j][0] = *reinterpret_cast<const float4*>(g);
+        xr[Q][j][1] = *reinterpret_cast<const float4*>(g + 4);
     };
+    auto x_load = [&](int j, const float* src, int Csrc) { x_load_s(X0{}, j, src, Csrc); };
     // transform + bf16 hi/lo split + LDS write of item j (raw values in xr, slice c) into window xdst
-    auto x_stage = [&](int j, int c, char* xdst) {
+    auto x_stage_s = [&](auto set, int j, int c, char* xdst) {
         if (ABL(64)) return;
+        constexpr int Q = decltype(set)::value;
         const char* pt = ptab + (c & 1) * pt_stride + it_pt[j];
-        float4 v0 = xform4<MODE>(xr[j][0], pt, ptv, ln_mu[j], ln_rs[j]);
-        float4 v1 = xform4<MODE>(xr[j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
+        float4 v0 = xform4<MODE>(xr[Q][j][0], pt, ptv, ln_mu[j], ln_rs[j]);
+        float4 v1 = xform4<MODE>(xr[Q][j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
         if constexpr (MODE == IN_SOFTMAX32) softmax32(v0, v1);
         uint4 hi, lo;
         split8(v0, v1, hi, lo);
@@ -361,6 +373,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         *reinterpret_cast<uint4*>(d) = hi;
         if constexpr (!PLAIN) *reinterpret_cast<uint4*>(d + 2 * CK) = lo;      // (PLAIN: the lo half of the split is dead code)
     };
+    auto x_stage = [&](int j, int c, char* xdst) { x_stage_s(X0{}, j, c, xdst); };
     auto slice_src = [&](int c, const float*& src, int& Csrc) {  // channel-concatenated input: two tensors
         const int cc = (c + cb) * CK;
         if (cc < p.C0) { src = p.in0 + cc + q8; Csrc = p.C0; } else { src = p.in1 + (cc - p.C0) + q8; Csrc = p.C1; }
@@ -445,12 +458,18 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
             else w_load(S0{}, HAll{}, k16_src(0, 1, 0), k16_src(0, 1, KS - 1));
         }
     } else {
-        // ---- prologue (any filter): slice 0 and slab 0 staged, slab 1 in flight
+        // ---- prologue (any filter): slice 0 and slab 0 staged, slab 1 in flight; with two register sets slice 1 is on its way too
         const float* src; int Csrc;
         slice_src(0, src, Csrc);
 #pragma unroll
         for (int j = 0; j < MAXI; ++j) x_load(j, src, Csrc);
         w_load(S0{}, HAll{}, k16_src(0, 0, 0), KS > 1 ? k16_src(0, 0, 1) : nullptr);
+        if constexpr (XD == 2) {
+            const float* s1; int C1;
+            slice_src(nchunks > 1 ? 1 : 0, s1, C1);          // (clamped: a redundant load when there is one slice only)
+#pragma unroll
+            for (int j = 0; j < MAXI; ++j) x_load_s(X1{}, j, s1, C1);
+        }
 #ifdef HD_STAMPS
         st_issue = HD_STAMP();
         __builtin_amdgcn_s_waitcnt(0x0070);
@@ -567,10 +586,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
             const int kk = k < nit ? k : nit - 1; const int c = kk / ntaps, tp = kk - c * ntaps;
             w_load(S0{}, HAll{}, k16_src(c, tp, 0), KS > 1 ? k16_src(c, tp, 1) : nullptr);
         };
-        auto slice = [&](int c, auto has_next) {
+        // PAR: parity of c = the register set that is free during slice c (it held slice c, staged at the end of slice c-1; with one set: the only one).
+        // Two sets: slice c+2 is requested into set PAR (clamped to the last slice past the end: a redundant load instead of a branch) and slice
+        // c+1 is staged from the other set; one set: slice c+1 is requested and staged within slice c.
+        auto slice = [&](int c, auto has_next, auto parc) {
             constexpr bool NEXT = decltype(has_next)::value;
+            using QL = std::integral_constant<int, XD == 2 ? decltype(parc)::value : 0>;          // set to load into
+            using QS = std::integral_constant<int, XD == 2 ? 1 - decltype(parc)::value : 0>;      // set to stage from
             const float* nsrc = nullptr; int nCsrc = 0;
-            if constexpr (NEXT) slice_src(c + 1, nsrc, nCsrc);
+            if constexpr (NEXT) slice_src(XD == 2 ? min(c + 2, nchunks - 1) : c + 1, nsrc, nCsrc);
             {
                 __syncthreads();         // slab `it` and the window of slice c are visible; nobody still reads slab it-1
                 w_store(S0{}, HAll{}, KS * (par ^ 1), KS * (par ^ 1) + 1);
@@ -578,7 +602,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
                 if constexpr (NEXT) {
                     pt_load(c + 1);
 #pragma unroll
-                    for (int j = 0; j < MAXI; ++j) x_load(j, nsrc, nCsrc);
+                    for (int j = 0; j < MAXI; ++j) x_load_s(QL{}, j, nsrc, nCsrc);
                 }
                 mfma_cluster(Xs, KS * par, 0);
                 par ^= 1; ++it;
@@ -597,11 +621,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
                 pt_store(c + 1);
                 __syncthreads();         // single window: every wave has finished the slice
 #pragma unroll
-                for (int j = 0; j < MAXI; ++j) x_stage(j, c + 1, Xs);
+                for (int j = 0; j < MAXI; ++j) x_stage_s(QS{}, j, c + 1, Xs);
             }
         };
-        for (int c = 0; c + 1 < nchunks; ++c) slice(c, std::true_type{});
-        slice(nchunks - 1, std::false_type{});
+        {
+            int c = 0;
+            for (; c + 2 < nchunks; c += 2) { slice(c, std::true_type{}, X0{}); slice(c + 1, std::true_type{}, std::integral_constant<int, 1>{}); }
+            if (c + 1 < nchunks) { slice(c, std::true_type{}, X0{}); slice(c + 1, std::false_type{}, std::integral_constant<int, 1>{}); }
+            else slice(c, std::false_type{}, X0{});
+        }
     }
     (void)w1; (void)w2; (void)w3; (void)v0; (void)v1; (void)v2; (void)v3; (void)u0; (void)u1; (void)u2; (void)u3; (void)pr1; (void)pr2; (void)wv; (void)wdst;
 #undef HD_WLOAD
@@ -626,7 +654,7 @@ template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 // (16-channel slices with the 256 x 64 tile: ~40 KB of LDS, so a third workgroup fits a CU if the registers allow -- at most 168.  The same cap on
 // the 128 x 128 variants with 16-channel slices everywhere measured a loss: 14.1 vs 13.45 ms per unet64 step.)
 // Only the plain loader fits 168 registers without scratch (the GroupNorm-apply loaders need 196: capped, they spill 12 registers -- tests/test_isa_guards.py).
-__global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE>() ? 3 : (NTAPS == 0 && MAXI > 4) ? 1 : 2)) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>() ? 3 : (NTAPS == 0 && MAXI > 4) ? 1 : 2)) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
     conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, false>(p);
 }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>

@@ -216,6 +216,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
 #endif
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+        // Residual rows of the whole round, requested BEFORE the accumulators are staged: fetched pass by pass (one ahead), each of the
+        // NPASS passes waited out most of an HBM round trip -- the 1x1 shortcut at 64 x 64 spent two thirds of a workgroup's life there
+        // (3.9 TB/s with the residual against 5.0 without).  Rows past the tile read pixel 0 (never used).
+        float4 rr_all[NPASS];
+        const bool pre_res = vec && nvalid > 0 && (p.ep & (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES)) != 0;
+        if (pre_res) {
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int lr = pass * RPP + rg;
+                const int pix = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
+                rr_all[pass] = *reinterpret_cast<const float4*>(p.res + (size_t)(pix < 0 ? 0 : pix) * p.Cout + n);
+            }
+        }
 #ifdef HD_STAMPS
         e0 = __builtin_readcyclecounter();
 #endif
@@ -264,18 +277,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     for (int m = 1; m < CQ; m <<= 1) x += __shfl_xor(x, m, 64);
                     return x;
                 };
-                auto fetch_res = [&](int pass) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {      // (fully unrolled: rr_all must stay in registers)
                     const int lr = pass * RPP + rg;
                     const int pix = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
-                    return *reinterpret_cast<const float4*>(p.res + (size_t)(pix < 0 ? 0 : pix) * p.Cout + n);
-                };
-                float4 n_rr = fetch_res(0);
-#pragma unroll 2
-                for (int pass = 0; pass < NPASS; ++pass) {
-                    const int lr = pass * RPP + rg;
-                    const int pix = rowpix[(lr >> 5) * 32 * TM + tm * 32 + (lr & 31)];
-                    const float4 rr = n_rr;
-                    if (pass + 1 < NPASS) n_rr = fetch_res(pass + 1);
+                    const float4 rr = rr_all[pass];
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
                     const float mean = rsum(v[0] + v[1] + v[2] + v[3]) * (1.f / BN);
@@ -338,9 +344,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     }
                 }
             } else if (vec) {
-                // General path: the residual / FiLM operands of pass i+1 are requested BEFORE pass i is stored, so the
-                // wait for them (vmcnt(1)) never includes the store that was issued after them.
-                float4 n_rr = make_float4(0.f, 0.f, 0.f, 0.f), n_sc = n_rr, n_sh = n_rr, n_ra = n_rr, n_rb = n_rr;
+                // General path: the residual rows were requested at the top of the round; per-row FiLM operands (several samples per tile only) of
+                // pass i+1 are requested BEFORE pass i is stored, so the wait for them never includes the store that was issued after them.
+                float4 n_sc = make_float4(0.f, 0.f, 0.f, 0.f), n_sh = n_sc, n_ra = n_sc, n_rb = n_sc;
                 // One sample per tile (every full-resolution layer): the per-(sample, channel) operands are the same for all rows --
                 // load them once instead of once per pass (vmcnt retires in order: every load in the pass loop is a wait on the stores
                 // and loads issued before it).
@@ -360,14 +366,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 auto fetch = [&](int pass) {
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
-                    const int pix = rowpix[m];
-                    const size_t o = (size_t)(pix < 0 ? 0 : pix) * p.Cout + n;
                     if (!one_b && (p.ep & (EP_FILM_SILU | EP_ADD_SILU))) {
                         const int fo = rowb[m] * p.ep_bstride + n;
                         n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
                         if (p.ep & EP_FILM_SILU) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                     }
-                    if (p.ep & (EP_RES | EP_RES_AFFINE_SILU)) n_rr = *reinterpret_cast<const float4*>(p.res + o);
                     if (!one_b && (p.ep & EP_RES_AFFINE_SILU)) {
                         const int fo = rowb[m] * p.res_bstride + n;
                         n_ra = *reinterpret_cast<const float4*>(p.resA + fo);
@@ -375,13 +378,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     }
                 };
                 fetch(0);
-#pragma unroll 2
-                for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {      // (fully unrolled: rr_all must stay in registers)
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
                     const int pix = rowpix[m];
                     const bool up = two && lr >= 32;
-                    const float4 rr = n_rr, sc = n_sc, sh = n_sh, ra = n_ra, rb = n_rb;
+                    const float4 rr = rr_all[pass], sc = n_sc, sh = n_sh, ra = n_ra, rb = n_rb;
                     if (pass + 1 < NPASS) fetch(pass + 1);
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};

@@ -417,39 +417,61 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
 // (src/hicdiff.py:217-226).  This kernel writes W'_b in the split-bf16 image layout of the conv kernel
 // ([16-channel k-step = 2 * head + d / 16][CoutPad][16 hi | 16 lo]); the conv's loader then applies the softmax (IN_SOFTMAX32).
 // permute != 0: the chained q kernel's own layout instead ([head][CoutPad][32 hi | 32 lo], d in accumulator order).
+// grid (B * heads, CoutPad / 64): a workgroup folds one head's context into 64 output rows.  The head's weight slice [32 e][64 o] and the
+// context sit in LDS; thread (o = tid & 63, dq = tid >> 6) accumulates d = 8 dq .. 8 dq + 7 (a wave shares its d's: the context reads are
+// broadcasts); the split results are assembled as the final byte image in LDS and leave with coalesced 16-byte stores.  (The first version --
+// one workgroup per head, weights read from global inside the dot products, 2-byte stores -- took 36 / 69 / 129 us at C = 64 / 128 / 256.)
 __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __restrict__ wout, const float* __restrict__ ctx, int CoutPad,
                                                                unsigned short* __restrict__ dst, int permute) {
     constexpr int D = 32;
     __shared__ float cs[D][D + 1];
-    const int bh = blockIdx.x, h = bh & 3, tid = threadIdx.x;       // heads = 4
+    __shared__ float ws[D][64];
+    __shared__ __attribute__((aligned(16))) unsigned short img[64 * 64];     // 8 KB: permute ? [64 o][32 hi | 32 lo] : [2 k-steps][64 o][16 hi | 16 lo]
+    const int bh = blockIdx.x, h = bh & 3, o0 = blockIdx.y * 64, tid = threadIdx.x;       // heads = 4
     for (int i = tid; i < D * D; i += 256) cs[i / D][i % D] = ctx[(size_t)bh * D * D + i];
+    for (int i = tid; i < D * 64; i += 256) ws[i >> 6][i & 63] = wout[(size_t)(h * D + (i >> 6)) * CoutPad + o0 + (i & 63)];   // packed fp32 [Cin = 128][CoutPad]
     __syncthreads();
-    const float* w = wout + (size_t)h * D * CoutPad;                 // packed fp32 [Cin = 128][CoutPad]
-    unsigned short* out = dst + (size_t)bh * CoutPad * 2 * D;        // [b][head][CoutPad][64]
-    for (int i = tid; i < CoutPad * D; i += 256) {
-        const int d = i % D, o = i / D;          // d fastest: the 32 lanes of an output row write 64 contiguous bytes
-        float acc = 0.f;
+    const int o = tid & 63, dq = tid >> 6;
+    float acc[8];
 #pragma unroll
-        for (int e = 0; e < D; ++e) acc += w[(size_t)e * CoutPad + o] * cs[d][e];
-        acc *= 0.17677669529663687f;                                 // dim_head ** -0.5
-        const __bf16 hi = (__bf16)acc;
-        const __bf16 lo = (__bf16)(acc - (float)hi);
-        // permute: d axis in the order an MFMA accumulator presents it as an operand (linattn_q_fused.hip):
-        // position 16*s + 8*half + 4*g + i  <-  d = 16*s + 8*g + 4*half + i
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll 8
+    for (int e = 0; e < D; ++e) {
+        const float wv = ws[e][o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wv * cs[dq * 8 + j][e];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int d = dq * 8 + j;
+        const float v = acc[j] * 0.17677669529663687f;               // dim_head ** -0.5
+        const __bf16 hi = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)hi);
         if (permute) {
+            // d axis in the order an MFMA accumulator presents it as an operand (linattn_q_fused.hip): position 16*s + 8*half + 4*g + i  <-  d = 16*s + 8*g + 4*half + i
             const int pos = (d & 16) | ((d & 4) << 1) | ((d & 8) >> 1) | (d & 3);
-            out[(size_t)o * 2 * D + pos] = __builtin_bit_cast(unsigned short, hi);
-            out[(size_t)o * 2 * D + D + pos] = __builtin_bit_cast(unsigned short, lo);
+            img[o * 64 + pos] = __builtin_bit_cast(unsigned short, hi);
+            img[o * 64 + D + pos] = __builtin_bit_cast(unsigned short, lo);
         } else {
-            unsigned short* row = out + ((size_t)(d >> 4) * CoutPad + o) * 32;
+            unsigned short* row = img + ((d >> 4) * 64 + o) * 32;
             row[d & 15] = __builtin_bit_cast(unsigned short, hi);
             row[16 + (d & 15)] = __builtin_bit_cast(unsigned short, lo);
         }
     }
+    __syncthreads();
+    // 8 KB out: permute: rows o0 .. o0+63 of [b][head][CoutPad][64 shorts] (contiguous); else two 4 KB runs, k-steps 2 h and 2 h + 1 of [b][8][CoutPad][32 shorts]
+    const uint4* src = reinterpret_cast<const uint4*>(img);
+    char* out = reinterpret_cast<char*>(dst) + (size_t)bh * CoutPad * 128;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = tid + k * 256;                                 // 16-byte piece of the image
+        char* g = permute ? out + (size_t)o0 * 128 + i * 16 : out + (size_t)(i >> 8) * CoutPad * 64 + (size_t)o0 * 64 + (i & 255) * 16;
+        *reinterpret_cast<uint4*>(g) = src[i];
+    }
 }
 
 int launch_linattn_fold_out(const float* wout_packed, const float* ctx, int B, int CoutPad, unsigned short* dst, hipStream_t st, int permute) {
-    hipLaunchKernelGGL(linattn_fold_out_kernel, dim3(B * 4), dim3(256), 0, st, wout_packed, ctx, CoutPad, dst, permute);
+    hipLaunchKernelGGL(linattn_fold_out_kernel, dim3(B * 4, CoutPad / 64), dim3(256), 0, st, wout_packed, ctx, CoutPad, dst, permute);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { hd_set_error(std::string("linattn_fold_out launch: ") + hipGetErrorString(e)); return -3; }
     return 0;
