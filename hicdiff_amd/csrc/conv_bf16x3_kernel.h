@@ -278,8 +278,15 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
             // every build that did so produced exact zeros in the low lane for the last 16 lanes of a wave on
             // large grids (tests/test_gpu_kernels.py::test_large_grid_*), every build that did not was clean.
             // Root cause not established (open questions).
+#ifdef HD_LN_INPLACE      // hazard bisect builds (tools/ln_zero_lane_bisect.sh): the statistics used in place, as hipcc allocates them
+            ln_rs[j] = st.y; ln_mu[j] = st.x;
+#if HD_LN_INPLACE > 1     // ... with every load retired before anything else happens
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#else
             asm volatile("v_mov_b32 %0, %1" : "=v"(ln_rs[j]) : "v"(st.y));
             asm volatile("v_mov_b32 %0, %1" : "=v"(ln_mu[j]) : "v"(st.x));
+#endif
         }
     }
 
