@@ -94,6 +94,9 @@ SYMBOLS = {
     "hd_train_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_train_param_count": (C.c_int, [_P, _P]),
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
+    "hd_train_stage_count": (C.c_int, [_P]),
+    "hd_train_slot_stage": (C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    "hd_train_stage_wait": (C.c_int, [_P, C.c_int, _P]),
     "hd_train_loss_backward": (C.c_int, [_P] * 6 + [C.c_int] + [_P] * 3 + [C.c_int, _P, _P]),
     "hd_adam_step": (C.c_int, [_P, _P, _P, _P, C.c_longlong, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, _P]),
     "hd_ddrm_x0": (C.c_int, [_P, _P, C.c_float, C.c_float, _P, C.c_size_t, _P]),

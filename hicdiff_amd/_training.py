@@ -4,7 +4,9 @@ The reference trains with `loss = diffusion(x); loss.backward(); optimizer.step(
 Here the same four lines run on the HIP engine: in train mode `GaussianDiffusion.forward` computes the loss AND every gradient in
 one `hd_train_loss_backward`, and returns a loss tensor whose `.backward()` hands the gradients to the parameters' `.grad`;
 `hicdiff_amd.optim.Adam.step()` is one `hd_adam_step` over the flat buffer.  The module's parameters become views of one flat
-fp32 tensor (state_dict keys, shapes and values unchanged).  torch owns the memory and, for N > 1 GPUs, the one all-reduce.
+fp32 tensor (state_dict keys, shapes and values unchanged).  torch owns the memory and, for N > 1 GPUs, the all-reduce:
+`StagedReducer` sums the gradients over the ranks one gradient stage (hd_train_stage_*) at a time on a side stream while the
+kernels of the later stages still run.
 """
 from __future__ import annotations
 
@@ -17,6 +19,84 @@ from . import _lib as L
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+
+def _dist_world() -> int:
+    d = torch.distributed
+    return d.get_world_size() if d.is_available() and d.is_initialized() else 1
+
+
+class StagedReducer:
+    """Data-parallel gradient sum over the ranks, overlapped with the walk back through the network.
+
+    The C trainer finishes its gradients back to front and records one event per gradient stage (include/hicdiff_hip.h "Gradient
+    stages").  For every stage, in stage order: a side stream waits for the stage's event (on the device), gathers the stage's
+    slots of the flat gradient buffer into one contiguous bucket, and starts one asynchronous all-reduce of the bucket (RCCL on
+    the GPU; the collectives of successive buckets queue behind each other while the compute stream is still producing the next
+    stage).  `finish()` scatters the sums back over the flat buffer and makes the current stream wait for all of it; the host
+    never blocks.  One bucket per stage rather than one collective per slot: xGMI ring all-reduces are latency-bound below a few
+    MB, and a stage of either network is 10-40 MB.  Every rank builds the same buckets in the same order (the stage map is a
+    function of the architecture alone), which is what the collectives need.
+
+    On CPU tensors (the gloo tests) there are no streams: the same packing, collectives and scatter run in program order."""
+
+    def __init__(self, grads: torch.Tensor, slots, slot_stage, group=None):
+        self.grads, self.group = grads, group
+        nst = max(slot_stage) + 1
+        self.runs = [[] for _ in range(nst)]                     # per stage: merged (offset, length) runs of the flat buffer
+        for (name, off, shape), k in sorted(zip(slots, slot_stage), key=lambda e: e[0][1]):
+            n = 1
+            for d in shape:
+                n *= d
+            runs = self.runs[k]
+            if runs and runs[-1][0] + runs[-1][1] == off:
+                runs[-1] = (runs[-1][0], runs[-1][1] + n)
+            else:
+                runs.append((off, n))
+        self.buckets = [torch.empty(sum(n for _, n in runs), dtype=grads.dtype, device=grads.device) for runs in self.runs]
+        self.cuda = grads.device.type == "cuda"
+        self.comm = torch.cuda.Stream(device=grads.device) if self.cuda else None
+        self.works = []
+
+    @property
+    def pending(self) -> bool:
+        return bool(self.works)
+
+    def _copy(self, k: int, to_bucket: bool):
+        pos, b = 0, self.buckets[k]
+        for off, n in self.runs[k]:
+            if to_bucket:
+                b[pos:pos + n].copy_(self.grads[off:off + n])
+            else:
+                self.grads[off:off + n].copy_(b[pos:pos + n])
+            pos += n
+
+    def launch(self, wait_stage=None):
+        """Queue pack + all-reduce of every stage.  wait_stage(k, stream_handle) makes the side stream wait for stage k's event."""
+        if self.works:
+            raise RuntimeError("StagedReducer.launch: the previous reduction was not finished")
+        import contextlib
+        for k in range(len(self.runs)):
+            if not self.runs[k]:
+                continue
+            with (torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()):
+                if wait_stage is not None:
+                    wait_stage(k, self.comm.cuda_stream if self.cuda else None)
+                self._copy(k, True)
+                self.works.append((k, torch.distributed.all_reduce(self.buckets[k], group=self.group, async_op=True)))
+
+    def finish(self):
+        """Sums back into the flat buffer; the current stream continues behind them."""
+        if not self.works:
+            return
+        import contextlib
+        with (torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()):
+            for k, w in self.works:
+                w.wait()                                         # GPU: the side stream waits for the collective's stream; CPU: blocks
+                self._copy(k, False)
+        self.works = []
+        if self.cuda:
+            torch.cuda.current_stream(self.grads.device).wait_stream(self.comm)
 
 
 class NativeTrainer:
@@ -65,6 +145,16 @@ class NativeTrainer:
             p._hd_flat = (self, off)
             self.params.append(p)
         self.anchor = torch.zeros((), device=self.device, requires_grad=True)      # gives the returned loss a grad_fn
+        stage = C.c_int()
+        self.slot_stage = []
+        for i in range(n):
+            if self.lib.hd_train_slot_stage(self.h, i, C.byref(stage)) != 0:
+                raise L.HdError(L.HD_EINVAL, "hd_train_slot_stage")
+            self.slot_stage.append(stage.value)
+        if max(self.slot_stage) + 1 != self.lib.hd_train_stage_count(self.h):
+            raise RuntimeError("hd_train_stage_count disagrees with the slot -> stage map")
+        self.reducer = None                # StagedReducer, made on the first step that runs under torch.distributed with > 1 rank
+        self.reduced_serial = -1           # serial of the last loss whose gradients were (or are being) summed over the ranks
 
     def __del__(self):
         try:
@@ -99,6 +189,7 @@ class NativeTrainer:
         # Gradient accumulation (several diffusion(x) / backward() pairs before one optimizer.step(), no zero_grad between): the
         # kernels overwrite the flat gradient buffer, and after the first backward() every p.grad IS a view of that buffer.  Carry
         # the gradients accumulated so far in a copy; backward() adds them back (as autograd's AccumulateGrad would).
+        self.reduce_finish()               # a reduction of the previous loss still in flight writes the buffer this step overwrites
         if getattr(self, "carry", None) is None and any(
                 p.grad is not None and p.grad.data_ptr() == self.grad_view(i).data_ptr() for i, p in enumerate(self.params)):
             self.carry = self.grads.clone()
@@ -109,7 +200,26 @@ class NativeTrainer:
         if rc != 0:
             raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode() + " / " + (self.lib.hd_last_error(None) or b"").decode())
         self.serial = getattr(self, "serial", 0) + 1
+        import os
+        if _dist_world() > 1 and os.environ.get("HICDIFF_DP_OVERLAP", "1") != "0":
+            # every kernel of the step is queued; queue the per-stage sums behind their events now, so that stage k travels over xGMI
+            # while stages k+1.. are still being computed.  (HICDIFF_DP_OVERLAP=0: one all-reduce of the whole buffer in Adam.step.)
+            if self.reducer is None:
+                self.reducer = StagedReducer(self.grads, self.slots, self.slot_stage)
+            with torch.cuda.device(self.device):
+                self.reducer.launch(self._wait_stage)
+            self.reduced_serial = self.serial
         return _NativeLoss.apply(self.anchor, self, self.loss.clone(), self.serial)
+
+    def _wait_stage(self, k, stream):
+        rc = self.lib.hd_train_stage_wait(self.h, k, C.c_void_p(stream))
+        if rc != 0:
+            raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
+
+    def reduce_finish(self):
+        if self.reducer is not None and self.reducer.pending:
+            with torch.cuda.device(self.device):
+                self.reducer.finish()
 
     def weights_changed(self):
         self.model.__dict__["_hd_weight_epoch"] = self.model.__dict__.get("_hd_weight_epoch", 0) + 1
@@ -129,6 +239,7 @@ class _NativeLoss(torch.autograd.Function):
         if ctx.serial != tr.serial:
             raise RuntimeError("this loss is stale: the gradient buffer holds the gradients of a later diffusion(x) call "
                                "(call loss.backward() before the next forward in train mode)")
+        tr.reduce_finish()                        # the sums over the ranks (if any) land before anything below touches the buffer
         one = bool((grad_out == 1).item())
         if not one:
             tr.grads.mul_(grad_out)

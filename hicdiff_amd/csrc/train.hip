@@ -1296,6 +1296,12 @@ struct hd_trainer {
     struct Slot { std::string name; size_t off, n; int ndim; long long shape[4]; };
     std::vector<Slot> slots;
     size_t nparams = 0;
+    // gradient stages (hd_train_stage_*): slot -> stage in completion order, one event per stage recorded by every step
+    std::vector<int> slot_stage;
+    std::vector<hipEvent_t> stage_ev;
+    std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
+    float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
+    const float* cur_grads = nullptr;     // the gradient buffer of the step being queued
     size_t o_head_w = 0, o_head_b = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_bt_w = 0, o_bt_b = 0, o_tail_w = 0, o_tail_b = 0;
     std::vector<size_t> o_mlp_w, o_mlp_b, o_conv_w, o_conv_b;
     // device memory
@@ -1340,15 +1346,37 @@ template <class T> static T* dev_alloc(hd_trainer* t, size_t n, bool zero = fals
     return (T*)p;
 }
 
+// gradient stages: one event per stage, created once the slot -> stage map exists
+static bool stage_events(hd_trainer* t) {
+    int n = 0;
+    for (int s : t->slot_stage) n = std::max(n, s + 1);
+    t->stage_ev.assign(n, nullptr);
+    for (auto& e : t->stage_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+}
+// Stage k's gradients are all in their slots at this point of the stream.  With a snapshot buffer set (hd_debug_train_stage_snapshot: tests) the
+// stage's slots are also copied there, in stream order right behind the event, so "nothing writes a slot after its stage's event" can be
+// checked without racing: the snapshot must equal the gradients the step ends with.
+static void stage_done(hd_trainer* t, int k, hipStream_t st) {
+    if (k < 0 || k >= (int)t->stage_ev.size()) return;
+    (void)hipEventRecord(t->stage_ev[k], st);
+    if (t->stage_snap && t->cur_grads)
+        for (size_t j = 0; j < t->slots.size(); ++j)
+            if (t->slot_stage[j] == k)
+                (void)hipMemcpyAsync(t->stage_snap + t->slots[j].off, t->cur_grads + t->slots[j].off, t->slots[j].n * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
 #include "train_unet.inc"
 
 extern "C" {
 
 const char* hd_train_last_error(const hd_trainer* t) { return t ? t->err.c_str() : t_err.c_str(); }
 
+
 void hd_train_destroy(hd_trainer* t) {
     if (!t) return;
     (void)hipDeviceSynchronize();         // nothing of this trainer may still be running when its buffers go
+    for (hipEvent_t e : t->stage_ev) if (e) (void)hipEventDestroy(e);
     for (void* p : t->owned) (void)hipFree(p);
     t->wg.destroy();
     if (t->unet) { t->unet->destroy(); delete t->unet; }
@@ -1365,7 +1393,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
         hd_trainer* t = new hd_trainer();
         t->arch = *a; t->device = device; t->B = B; t->S = S;
         t->unet = new UnetTrainer();
-        if (!t->unet->init(t, B, S)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the UNet trainer"); }
+        if (!t->unet->init(t, B, S) || !stage_events(t)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the UNet trainer"); }
         *out = t;
         return HD_OK;
     }
@@ -1399,6 +1427,21 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     add_slot(t, "tail.weight", {1, F, 3, 3}, &t->o_tail_w);
     add_slot(t, "tail.bias", {1}, &t->o_tail_b);
     t->o_bt_w = t->o_conv_w[n]; t->o_bt_b = t->o_conv_b[n];
+    {   // Gradient stages (hd_train_stage_*).  The walk back finishes body_tail / tail first, then the blocks n-1 .. 0 (a block's conv weight is
+        // final once both uses of the shared convolution have added their gradient), and only at the very end the FiLM projections of ALL blocks,
+        // the time MLP and the head: four stages of blocks (stage 0 also holds body_tail and tail) + one final stage.
+        const int NS = std::min(4, n), per = (n + NS - 1) / NS;
+        t->slot_stage.assign(t->slots.size(), NS);
+        t->block_stage_end.assign(n, -1);
+        for (int i = 0; i < n; ++i) {
+            const int k = std::min(NS - 1, (n - 1 - i) / per);
+            for (size_t j = 0; j < t->slots.size(); ++j)
+                if (t->slots[j].off == t->o_conv_w[i] || t->slots[j].off == t->o_conv_b[i]) t->slot_stage[j] = k;         // conv.proj.weight / bias of block i
+            if (i == 0 || std::min(NS - 1, (n - i) / per) != k) t->block_stage_end[i] = k;   // the next block walked (i - 1) belongs to a later stage
+        }
+        for (size_t j = 0; j < t->slots.size(); ++j)
+            if (t->slots[j].off >= t->o_conv_w[n]) t->slot_stage[j] = 0;                  // body_tail, tail: the last four slots
+    }
 
     bool ok = true;
     auto need = [&](void* p) { if (!p) ok = false; return p; };
@@ -1435,7 +1478,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->fpart = (float*)need(dev_alloc<float>(t, (size_t)B * nchunk * 2 * F));
     t->spart = (float*)need(dev_alloc<float>(t, (size_t)B * ((S + 7) / 8) * F * 18));
     t->mpart = (float*)need(dev_alloc<float>(t, (size_t)n * B * t->tdim));
-    if (!ok) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 2 per block)"); }
+    if (!ok || !stage_events(t)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 2 per block)"); }
     *out = t;
     return HD_OK;
 }
@@ -1451,6 +1494,27 @@ int hd_train_param_count(const hd_trainer* t, long long* total_floats) {
     if (!t) return HD_EINVAL;
     if (total_floats) *total_floats = (long long)t->nparams;
     return (int)t->slots.size();
+}
+
+int hd_train_stage_count(const hd_trainer* t) { return t ? (int)t->stage_ev.size() : HD_EINVAL; }
+
+int hd_train_slot_stage(const hd_trainer* t, int slot, int* stage) {
+    if (!t || !stage || slot < 0 || slot >= (int)t->slot_stage.size()) return HD_EINVAL;
+    *stage = t->slot_stage[slot];
+    return HD_OK;
+}
+
+// `stream` waits (on the device; the host does not block) until the last queued step has written every gradient of `stage`.
+int hd_train_stage_wait(hd_trainer* t, int stage, void* stream) {
+    if (!t || stage < 0 || stage >= (int)t->stage_ev.size()) return HD_EINVAL;
+    if (hipStreamWaitEvent((hipStream_t)stream, t->stage_ev[stage], 0) != hipSuccess) return tfail(t, HD_EHIP, "hipStreamWaitEvent failed");
+    return HD_OK;
+}
+
+int hd_debug_train_stage_snapshot(hd_trainer* t, float* snapshot) {
+    if (!t) return HD_EINVAL;
+    t->stage_snap = snapshot;
+    return HD_OK;
 }
 
 int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long* offset, long long* shape4, int* ndim) {
@@ -1492,6 +1556,7 @@ static int colsum(hd_trainer* tr, float scale, bool accumulate, float* db, hipSt
 extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float* grads, const float* x_start, const float* cond, const void* t, int t_kind,
                                       const float* noise, const float* a_t, const float* s_t, int l2, float* loss, void* stream) {
     if (!tr || !params || !grads || !x_start || !t || !noise || !a_t || !s_t || !loss) return HD_EINVAL;
+    tr->cur_grads = grads;
     if (tr->unet) {
         if ((tr->arch.self_condition != 0) != (cond != nullptr)) return tfail(tr, HD_EINVAL, "cond must be given iff self_condition");
         if ((t_kind == HD_T_FLOAT32) != (tr->arch.sr3 != 0)) return tfail(tr, HD_EINVAL, "SR3 nets take the continuous noise level (float32); the others integer timesteps");
@@ -1611,6 +1676,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         float* nxt = (dx == tr->g2) ? tr->Y : tr->g2;                            // Y is free once its gradients are taken; g1 keeps dY
         TR_TRY(conv3(tr, tr->bwd[i], da, nxt, EP_RES, 1.f, dx, st));            // dx_i = dgrad(du) + dx_{i+1}
         dx = nxt;
+        stage_done(tr, tr->block_stage_end[i], st);
     }
     // head: d(head output) = dx + dY (the skip r); dW[co][cin][tap] = sum_p in_cin[p + tap] d[p][co]
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, dY, n4, da);
@@ -1635,6 +1701,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((F + 255) / 256, TD, 1), dim3(256), 0, st, tr->dh1, TD, tr->emb, F, B, F, TD, 0, grads + tr->o_t1w, grads + tr->o_t1b,
                        (size_t)0, (size_t)0, (size_t)0);
     TR_TRY(check_launch("time mlp backward"));
+    stage_done(tr, (int)tr->stage_ev.size() - 1, st);           // head, time MLP and every block's FiLM projection: the last stage
     return HD_OK;
 }
 

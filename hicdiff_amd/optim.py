@@ -1,6 +1,7 @@
 """`optim.Adam(diffusion.parameters(), lr=2e-5)` of train.py:111 on the HIP engine: one `hd_adam_step` over the flat
 parameter buffer of the native trainer (hicdiff_amd/_training.py).  With torch.distributed initialised the flat gradient is
-summed over ranks first (one RCCL all-reduce of the whole buffer) and the mean is taken inside the Adam kernel."""
+summed over ranks first -- stage by stage behind the backward pass (hicdiff_amd/_training.py StagedReducer), or, with
+HICDIFF_DP_OVERLAP=0, by one RCCL all-reduce of the whole buffer here -- and the mean is taken inside the Adam kernel."""
 from __future__ import annotations
 
 import ctypes as C
@@ -49,7 +50,9 @@ class Adam:
             k += 1
             scale = 1.0
             if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-                torch.distributed.all_reduce(tr.grads)
+                tr.reduce_finish()
+                if tr.reduced_serial != tr.serial:                 # not summed stage by stage while the backward pass ran
+                    torch.distributed.all_reduce(tr.grads)
                 scale = 1.0 / torch.distributed.get_world_size()
             lr = float(self.param_groups[0]["lr"])
             with torch.cuda.device(tr.device):

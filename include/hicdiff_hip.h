@@ -280,6 +280,18 @@ int hd_train_loss_backward(hd_trainer* t, const float* params, float* grads, con
                            const void* timesteps, int t_kind, const float* noise, const float* a_t, const float* s_t, int l2, float* loss,
                            void* stream);
 
+/* Gradient stages: overlapping the data-parallel all-reduce with the backward pass (train.py:131-134 under torchrun).
+ * hd_train_loss_backward produces the gradients back to front; the trainer cuts its parameter slots into a few stages in the order their
+ * gradients become FINAL (stage 0 first: the output end of the network; the last stage: the time MLP, the FiLM projections and the first
+ * convolution, which are finished at the very end) and records one event per stage on the step's stream behind the last kernel that writes
+ * a gradient of that stage.  A caller reduces stage k while the kernels of the later stages still run:
+ *   hd_train_stage_count   number of stages (>= 1)
+ *   hd_train_slot_stage    stage of parameter slot i (hd_train_param_slot order)
+ *   hd_train_stage_wait    make `stream` (a hipStream_t) wait for stage k of the LAST hd_train_loss_backward: hipStreamWaitEvent, no host wait */
+int hd_train_stage_count(const hd_trainer* t);
+int hd_train_slot_stage(const hd_trainer* t, int slot, int* stage);
+int hd_train_stage_wait(hd_trainer* t, int stage, void* stream);
+
 /* torch.optim.Adam without weight decay / amsgrad over one flat array, one launch: g = grads * grad_scale (1/world after a
  * summing all-reduce); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).
  * step counts from 1.  No context needed. */

@@ -67,6 +67,11 @@ int hd_debug_ws_bwd(const float* w, const float* dwhat, int Cout, int n, float* 
 int hd_debug_first_conv_wgrad(const float* g, const float* in0, const float* in1, int J, int B, int S, int C, int KS, float* dW, void* stream);
 int hd_debug_rowdot_bwd(const float* x, const float* dout, const float* w, long long P, int C, float* dx, float* dw, void* stream);
 
+/* Gradient stages (hd_train_stage_*): with a snapshot buffer set (float[total params], device; NULL = off) every hd_train_loss_backward copies a
+ * stage's slots into it in stream order right behind that stage's event.  The snapshot equals the step's final gradients iff no kernel writes
+ * a slot after its stage's event -- the property an all-reduce that starts at the event relies on. */
+int hd_debug_train_stage_snapshot(hd_trainer* t, float* snapshot);
+
 /* Gradient routing of the resampling layers: which == 1: 2x2 sum-pool (g [B,2H,2W,C] -> dx [B,H,W,C]); which == 2: pixel-shuffle (g [B,H,W,4C] ->
  * dx [B,2H,2W,C], g's channel c*4 + p1*2 + p2 goes to pixel (2y+p1, 2x+p2)).  C here is dx's channel count. */
 int hd_debug_resample_bwd(const float* g, int B, int H, int W, int C, int which, float* dx, void* stream);

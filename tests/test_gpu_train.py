@@ -277,7 +277,7 @@ def test_train_cli_trains_and_writes_reference_checkpoints(tmp_path, capsys):
 
 def test_train_two_ranks_stay_in_sync(tmp_path):
     """The N-rank path on the one GPU of the box (gloo, both ranks on device 0): ranks draw different batches, timesteps and
-    noise, all-reduce the flat gradient once per step, and must hold identical parameters at the end."""
+    noise, sum the flat gradient over the ranks every step (stage by stage behind the backward pass), and must hold identical parameters at the end."""
     import json
     import os
     import subprocess
@@ -301,6 +301,11 @@ def test_train_two_ranks_stay_in_sync(tmp_path):
     assert single.returncode == 0, single.stderr[-2000:]
     one = [json.loads(l) for l in single.stdout.splitlines() if "param_sum" in l][0]
     assert (one["param_sum"], one["param_abs_sum"]) != sums[0]            # the two-rank run really averaged different gradients
+    # the stage-by-stage sums behind the backward pass (the default above) and one all-reduce of the whole buffer in Adam.step agree bit for bit
+    whole = subprocess.run([("29733" if c == "29731" else c) for c in cmd], env=dict(env, HICDIFF_DP_OVERLAP="0"), capture_output=True, text=True, timeout=600)
+    assert whole.returncode == 0, whole.stderr[-2000:]
+    sums0 = {json.loads(l)["rank"]: (json.loads(l)["param_sum"], json.loads(l)["param_abs_sum"]) for l in whole.stdout.splitlines() if l.startswith("{") and "param_sum" in l}
+    assert sums0 == sums
 
 
 def test_train_plain_bf16_option():
@@ -729,6 +734,61 @@ def test_unet_train_full_network_properties_and_loop():
     with torch.no_grad():
         after = d.model(x0, t, lq)
     assert rel_err(before, after) > 1e-3
+
+
+@pytest.mark.parametrize("net", ["hicedrn", "unet", "unet_small"])
+def test_gradient_stages_are_final_at_their_event(net):
+    """Gradient stages (include/hicdiff_hip.h): every parameter slot belongs to one stage; the stages' events are recorded in stage order;
+    and -- what an all-reduce starting at the event relies on -- no kernel writes a slot after its stage's event.  The trainer's debug
+    snapshot copies each stage's slots in stream order right behind its event: the snapshot must equal the gradients the step ends with,
+    bit for bit, and those must equal the gradients of the same step taken without any of this (the golden / oracle tests run that way)."""
+    import ctypes as C
+    from hicdiff_amd import _lib as L
+    from hicdiff_amd._training import trainer_for
+    if net == "hicedrn":
+        d, B, S = _diffusion("cond", 6, 16), 3, 16                      # six blocks: four block stages of 2, 2, 1, 1 + the final stage
+    elif net == "unet":
+        d, B, S = _unet_diffusion("cond", 64, (1, 2, 4, 8), 32), 2, 32
+    else:
+        d, B, S = _unet_diffusion("uncond", 16, (1, 2), 16), 2, 16
+    d.train()
+    x0, lq = tiles(71, B, S).cuda(), tiles(72, B, S).cuda()
+    gen = torch.Generator().manual_seed(5)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()
+    cond = net != "unet_small"
+    step = lambda: d.p_losses([lq, x0], t, eps) if cond else d.p_losses(x0, t, eps)
+    step().backward()
+    tr = trainer_for(d.model, B, S)
+    plain = tr.grads.clone()
+    lib = L.load()
+    nst = lib.hd_train_stage_count(tr.h)
+    assert 2 <= nst <= 5 and sorted(set(tr.slot_stage)) == list(range(nst))      # no empty stage, every slot mapped
+    names = [s[0] for s in tr.slots]
+    last = [n for n, k in zip(names, tr.slot_stage) if k == nst - 1]
+    first = [n for n, k in zip(names, tr.slot_stage) if k == 0]
+    if net == "hicedrn":
+        assert "tail.weight" in first and "body_tail.weight" in first and "head.weight" in last
+        assert all(k == nst - 1 for n, k in zip(names, tr.slot_stage) if "mlp" in n)             # FiLM projections: finished at the very end
+    else:
+        assert "final_conv.weight" in first and "init_conv.weight" in last and "time_mlp.1.weight" in last
+    fn = lib.hd_debug_train_stage_snapshot
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_void_p]
+    snap = torch.full_like(tr.grads, float("nan"))
+    assert fn(tr.h, C.c_void_p(snap.data_ptr())) == 0
+    try:
+        tr.grads.fill_(float("nan"))
+        step().backward()
+        torch.cuda.synchronize()
+    finally:
+        fn(tr.h, None)
+    assert not torch.isnan(snap).any(), "a slot was in no stage's snapshot"
+    assert torch.equal(snap, tr.grads), "a gradient slot was written after its stage's event"
+    assert torch.equal(tr.grads, plain)
+    # a side stream that waits for stage 0 only may read stage 0's slots: the wait itself must succeed and order after the event
+    side = torch.cuda.Stream()
+    assert lib.hd_train_stage_wait(tr.h, 0, C.c_void_p(side.cuda_stream)) == 0
+    assert lib.hd_train_stage_wait(tr.h, nst, C.c_void_p(side.cuda_stream)) == L.HD_EINVAL
+    side.synchronize()
 
 
 def test_train_cli_unet(tmp_path, capsys):

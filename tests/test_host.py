@@ -202,7 +202,9 @@ class FakeTrainer:                               # what optim.Adam touches of a 
         self.grads = torch.full((8,), float(rank + 1))          # rank 0: ones, rank 1: twos
         self.params = []
         self.changed = 0
+        self.serial, self.reduced_serial = 1, -1                 # not reduced stage by stage (no native step ran): Adam.step does it
     def grad_view(self, i): return self.grads[4 * i:4 * i + 4]
+    def reduce_finish(self): pass
     def weights_changed(self): self.changed += 1
 model = object()
 tr = FakeTrainer(model)
@@ -230,6 +232,69 @@ def test_training_gradient_all_reduce_world_size_2_gloo(tmp_path):
     folded into the Adam launch, no launch after zero_grad.  The HIP library is replaced by a recorder (the kernels are covered on the GPU)."""
     script = tmp_path / "train_worker.py"
     script.write_text(_TRAIN_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out.decode()
+        assert b"ok" in out
+
+
+_STAGED_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+from hicdiff_amd._training import StagedReducer
+
+# a layout shaped like the hicedrn trainer's: [head | time MLP | per block (film, conv) | body_tail, tail]; conv slots of the blocks are final
+# back to front (stage 0 with the tail, stage 1), everything else at the very end (stage 2)
+sizes  = [7, 5, 11, 3, 13, 3, 11, 3, 13, 3, 17, 2]
+stages = [2, 2, 2,  2, 1,  1, 2,  2, 0,  0, 0,  0]
+slots, off = [], 0
+for i, n in enumerate(sizes):
+    slots.append((f"p{i}", off, (n,)))
+    off += n
+g = torch.Generator().manual_seed(100 + rank)
+mine = torch.randn(off, generator=g)
+both = sum(torch.randn(off, generator=torch.Generator().manual_seed(100 + r)) for r in range(world))
+grads = mine.clone()
+red = StagedReducer(grads, slots, stages)
+assert red.runs[0] == [(sum(sizes[:8]), 13 + 3 + 17 + 2)], red.runs[0]           # adjacent slots of one stage merge into one run
+assert red.runs[1] == [(sum(sizes[:4]), 16)], red.runs[1]
+assert [b.numel() for b in red.buckets] == [35, 16, sum(sizes) - 51]
+order = []
+red.launch(lambda k, stream: order.append(k))
+assert order == [0, 1, 2] and red.pending                                          # stage order = the order the walk back finishes them
+try:
+    red.launch()
+    raise SystemExit("a second launch before finish() must be refused")
+except RuntimeError:
+    pass
+red.finish()
+assert not red.pending
+assert torch.equal(grads, both), (grads - both).abs().max()                       # every element summed exactly once
+red.finish()                                                                       # idempotent
+# a second step through the same buckets
+grads.copy_(mine)
+red.launch()
+red.finish()
+assert torch.equal(grads, both)
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_staged_gradient_reduction_world_size_2_gloo(tmp_path):
+    """hicdiff_amd/_training.py StagedReducer on CPU: slots grouped by gradient stage into contiguous buckets, one asynchronous all-reduce per
+    stage in stage order, sums scattered back so that every element of the flat buffer is summed exactly once; reusable step after step."""
+    script = tmp_path / "staged_worker.py"
+    script.write_text(_STAGED_WORKER)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
