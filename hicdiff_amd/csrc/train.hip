@@ -1300,6 +1300,7 @@ struct hd_trainer {
     std::vector<int> slot_stage;
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
+    int slot_stage_of_block(int i) const { return (nres - 1 - i) * std::min(4, nres) / nres; }
     float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
     const float* cur_grads = nullptr;     // the gradient buffer of the step being queued
     size_t o_head_w = 0, o_head_b = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_bt_w = 0, o_bt_b = 0, o_tail_w = 0, o_tail_b = 0;
@@ -1428,16 +1429,19 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     add_slot(t, "tail.bias", {1}, &t->o_tail_b);
     t->o_bt_w = t->o_conv_w[n]; t->o_bt_b = t->o_conv_b[n];
     {   // Gradient stages (hd_train_stage_*).  The walk back finishes body_tail / tail first, then the blocks n-1 .. 0 (a block's conv weight is
-        // final once both uses of the shared convolution have added their gradient), and only at the very end the FiLM projections of ALL blocks,
-        // the time MLP and the head: four stages of blocks (stage 0 also holds body_tail and tail) + one final stage.
-        const int NS = std::min(4, n), per = (n + NS - 1) / NS;
+        // final once both uses of the shared convolution have added their gradient; the FiLM projections of a stage's blocks are taken in one
+        // launch when the stage's last block is done), and at the very end the time MLP and the head: four stages of blocks (stage 0 also
+        // holds body_tail and tail) + one small final stage.
+        const int NS = std::min(4, n);
+        auto stage_of = [&](int i) { return t->slot_stage_of_block(i); };            // blocks n-1 .. 0 spread evenly over stages 0 .. NS-1, none empty
         t->slot_stage.assign(t->slots.size(), NS);
         t->block_stage_end.assign(n, -1);
         for (int i = 0; i < n; ++i) {
-            const int k = std::min(NS - 1, (n - 1 - i) / per);
+            const int k = stage_of(i);
             for (size_t j = 0; j < t->slots.size(); ++j)
-                if (t->slots[j].off == t->o_conv_w[i] || t->slots[j].off == t->o_conv_b[i]) t->slot_stage[j] = k;         // conv.proj.weight / bias of block i
-            if (i == 0 || std::min(NS - 1, (n - i) / per) != k) t->block_stage_end[i] = k;   // the next block walked (i - 1) belongs to a later stage
+                if (t->slots[j].off == t->o_conv_w[i] || t->slots[j].off == t->o_conv_b[i] || t->slots[j].off == t->o_mlp_w[i] || t->slots[j].off == t->o_mlp_b[i])
+                    t->slot_stage[j] = k;                                             // block i: the shared convolution and the FiLM projection
+            if (i == 0 || stage_of(i - 1) != k) t->block_stage_end[i] = k;             // the next block walked (i - 1) belongs to a later stage
         }
         for (size_t j = 0; j < t->slots.size(); ++j)
             if (t->slots[j].off >= t->o_conv_w[n]) t->slot_stage[j] = 0;                  // body_tail, tail: the last four slots
@@ -1676,7 +1680,15 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         float* nxt = (dx == tr->g2) ? tr->Y : tr->g2;                            // Y is free once its gradients are taken; g1 keeps dY
         TR_TRY(conv3(tr, tr->bwd[i], da, nxt, EP_RES, 1.f, dx, st));            // dx_i = dgrad(du) + dx_{i+1}
         dx = nxt;
-        stage_done(tr, tr->block_stage_end[i], st);
+        if (tr->block_stage_end[i] >= 0) {
+            // the stage's blocks are i .. hi: their FiLM projections (Linear(SiLU(temb)) per block) in one launch, then the stage's event
+            int hi = i;
+            while (hi + 1 < n && tr->slot_stage_of_block(hi + 1) == tr->block_stage_end[i]) ++hi;
+            hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, FW, hi - i + 1), dim3(256), 0, st, tr->dfilm + (size_t)i * B * FW, FW, tr->temb, TD, B, TD, FW,
+                               sr3 ? 0 : 1, grads + tr->o_mlp_w[i], grads + tr->o_mlp_b[i], (size_t)B * FW, lstride, lstride);
+            TR_TRY(check_launch("film projection wgrad"));
+            stage_done(tr, tr->block_stage_end[i], st);
+        }
     }
     // head: d(head output) = dx + dY (the skip r); dW[co][cin][tap] = sum_p in_cin[p + tap] d[p][co]
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dx, dY, n4, da);
@@ -1687,9 +1699,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     hipLaunchKernelGGL(sum_rows_kernel, dim3((F + 255) / 256, B * S), dim3(256), 0, st, da, S, F, 1.f, 0, tr->colpart);
     TR_TRY(check_launch("head wgrad"));
     TR_TRY(colsum(tr, 1.f, false, grads + tr->o_head_b, st));
-    // FiLM projections (Linear(SiLU(temb)) per block) and the time MLP
-    hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, FW, n), dim3(256), 0, st, tr->dfilm, FW, tr->temb, TD, B, TD, FW, sr3 ? 0 : 1, grads + tr->o_mlp_w[0],
-                       grads + tr->o_mlp_b[0], (size_t)B * FW, lstride, lstride);
+    // the time MLP (the weight gradients of the FiLM projections were taken stage by stage above)
     hipLaunchKernelGGL(lin_bwd_x_kernel, dim3((TD + 255) / 256, B, n), dim3(256), 0, st, tr->dfilm, FW, params + tr->o_mlp_w[0], B, TD, FW, (const float*)nullptr, 0,
                        0, 0, tr->mpart, TD, (size_t)B * FW, lstride, (size_t)B * TD);
     hipLaunchKernelGGL(sum_rows_kernel, dim3((unsigned)(((size_t)B * TD + 255) / 256), 1), dim3(256), 0, st, tr->mpart, n, B * TD, 1.f, 0, tr->dst);
