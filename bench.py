@@ -8,6 +8,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --full-chain                   (time all 1000 steps of one chain; also implied by --steps >= 1000)
+    python bench.py --gpus N --workload hicedrn64 --total-tiles 256      (strong-scaling form of BASELINE configs[3]: 256/N tiles per GPU)
 
 A "step" is one pass of the hot path over one batch: the epsilon-network forward plus the fused
 posterior update for B tiles (one hd_ddpm_step call).  All steps of a chain cost the same, so
@@ -164,7 +165,8 @@ def cpu_baseline(w, budget_s=20.0):
 def bench_train(args):
     """--workload hicedrn64_train: training tiles / second of the native hicedrn step.
     A step = `loss = diffusion([lq, hq]); loss.backward(); optimizer.step(); optimizer.zero_grad()` (train.py:120-134) on synthetic
-    tiles resident in HBM; data parallel under torchrun (one all-reduce of the flat gradient per step), weak scaling."""
+    tiles resident in HBM; data parallel under torchrun (the flat gradient is summed over the ranks stage by stage while the backward pass
+    still runs: hicdiff_amd/_training.py StagedReducer), weak scaling."""
     rank, dev, world, dist = rank_env(args)
     from hicdiff_amd.hicdiff_condition import GaussianDiffusion
     from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
@@ -249,7 +251,7 @@ def bench_train(args):
             "data": "synthetic",
             "config": {"workload": (f"hicedrn64_train: hicedrn x{blocks} blocks" if args.train_arch == "hicedrn" else "hicedrn64_train --train-arch unet: UNet(64, (1,2,4,8))") +
                                    f", conditional, {batch} tiles of 1x{tile}x{tile} per GPU, Adam lr 2e-5",
-                       "tiles_per_gpu": batch, "tile": tile, "parallelism": f"data-parallel x{world}, one flat-gradient all-reduce per step"},
+                       "tiles_per_gpu": batch, "tile": tile, "parallelism": f"data-parallel x{world}, gradients summed stage by stage behind the backward pass (StagedReducer)"},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["TFLOPs"] if dom else None, "peak": round(PEAK_BF16_MFMA_TFLOPS / per_product, 1),
                          "unit": "TFLOP/s", "frac": round(kernels[dom]["TFLOPs"] / (PEAK_BF16_MFMA_TFLOPS / per_product), 4) if dom else None, "traffic": None,
                          "avg_launch_us": kernels[dom]["avg_launch_us"] if dom else None,
@@ -336,6 +338,9 @@ def main():
     ap.add_argument("--matrix-size", type=int, default=24896, help="tiles: matrix side (chr1 at 10 kb)")
     ap.add_argument("--res", type=int, default=10000, help="tiles: bin size")
     ap.add_argument("--batch", type=int, default=None, help="tiles per GPU (default: the workload's)")
+    ap.add_argument("--total-tiles", type=int, default=None,
+                    help="strong-scaling form (BASELINE configs[3]: 256 hicedrn tiles sharded over the node): the job is this many tiles in all, "
+                         "total/N per GPU; reported with \"scaling\": \"strong\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
     ap.add_argument("--full-chain", action="store_true", help="time a whole chain: --steps becomes 1000 (t = 999 .. 0)")
@@ -356,6 +361,10 @@ def main():
     w = dict(WORK[args.workload])
     if args.batch:
         w["B"] = args.batch
+    if args.total_tiles:
+        if args.batch or args.total_tiles % args.gpus:
+            raise SystemExit("--total-tiles: the tiles are dealt evenly, total % gpus must be 0, and --batch is then implied")
+        w["B"] = args.total_tiles // args.gpus
     rank, device, world, dist = rank_env(args)
 
     from hicdiff_amd import _lib as L
@@ -472,11 +481,12 @@ def main():
         out = {
             "metric": "denoised Hi-C tiles/sec (1000-step reverse)", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.total_tiles else "weak", "vs_baseline": None,
             "dtype": "f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
                                    f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
                        "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
+                       **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
                        "timed_region": ("one whole chain, t = 999 .. 0" if args.steps == T_CHAIN else
                                         f"{args.steps} consecutive steps from t = 999 (every step costs the same; see `sustained`)")},
             "roofline": roofline,

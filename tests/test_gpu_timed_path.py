@@ -376,3 +376,26 @@ def test_bench_two_ranks_self_launched_on_one_gpu():
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
     assert line["config"]["tiles_per_gpu"] == 4 and line["value"] > 0 and "all_gather_ms" in line
     assert abs(line["value"] - 2 * 4 / (1000 * line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+
+
+def test_bench_strong_scaling_form_two_ranks():
+    """`--total-tiles T` (BASELINE configs[3]'s "256 tiles sharded across the node"): T/N tiles per rank, value = T tiles over the chain time,
+    reported as strong scaling; an uneven deal is refused before any GPU work."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HICDIFF_BENCH_BACKEND="gloo", HICDIFF_DEVICE="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    base = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "unet40", "--no-cpu-baseline",
+            "--sustained-budget", "0"]
+    out = subprocess.run(base + ["--total-tiles", "6"], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["config"]["tiles_per_gpu"] == 3 and line["config"]["total_tiles"] == 6
+    assert abs(line["value"] - 6 / (1000 * line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
+    bad = subprocess.run(base + ["--total-tiles", "7"], env=env, capture_output=True, timeout=120)
+    assert bad.returncode != 0 and b"total % gpus" in bad.stderr
