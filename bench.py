@@ -349,6 +349,8 @@ def main():
     args = ap.parse_args()
     if args.full_chain:
         args.steps = T_CHAIN
+    if args.total_tiles and (args.batch or args.total_tiles % args.gpus):
+        raise SystemExit("--total-tiles: the tiles are dealt evenly, total % gpus must be 0, and --batch is then implied")
     if args.gpus > 1 and "RANK" not in os.environ:
         # not under a launcher: start the N rank processes here.  This process has not touched the GPU and never will.
         from hicdiff_amd.sharding import launch_ranks
@@ -362,8 +364,6 @@ def main():
     if args.batch:
         w["B"] = args.batch
     if args.total_tiles:
-        if args.batch or args.total_tiles % args.gpus:
-            raise SystemExit("--total-tiles: the tiles are dealt evenly, total % gpus must be 0, and --batch is then implied")
         w["B"] = args.total_tiles // args.gpus
     rank, device, world, dist = rank_env(args)
 
