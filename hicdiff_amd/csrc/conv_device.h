@@ -34,6 +34,7 @@ struct ConvKArgs {
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     const float* ep_ln_g; unsigned long long w_bstride; float* ln_stats_out;
     float* out; float* gn_part; int gn_slots;
+    GnFinArgs fin; int gn_direct;   // gn_direct: the workgroup holds every pixel of its sample(s): write the GroupNorm affine (fin) instead of leaving it to gn_finalize
     int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
     int m16;      // bf16x3 kernel family: 1 = the launch runs on 16 x 16 MFMA tiles (row -> pixel maps are laid out for 16-row operand blocks)
@@ -186,6 +187,32 @@ __device__ __forceinline__ float4 transform4(const ConvKArgs& p, float4 v, int c
 //   thread -> 4 fixed output channels (cq) and rows rg, rg + RPP, ...; GroupNorm per-channel partial sums
 //   are accumulated along those rows and reduced over the row groups in a fixed order: one slot per tile.
 // Acc: f32x16[TM][TN] (32 x 32 MFMA tiles) or f32x4[2 TM][2 TN] (16 x 16 tiles: col = lane & 15, row = 4 * (lane >> 4) + reg).
+// GroupNorm finalize by the producer (GnFinArgs): every lane holds one channel's (sum, sum of squares) over ALL pixels of sample b; lanes of
+// a wave hold consecutive channels starting at a multiple of 64 and a group is cg = C / groups channels, a power of two <= 64, so a group
+// never straddles a wave.  fp64 butterfly over the group's lanes (a fixed order), then what gn_finalize_kernel (small_kernels.hip) writes:
+// A = rstd gamma [(scale + 1)], Bv = (beta - mean rstd gamma) [(scale + 1) + shift], E = SR3's additive term.  Call with whole waves.
+__device__ __forceinline__ void gn_direct_finalize(const GnFinArgs& f, int b, int c, int C, int HW, float sum, float sumsq) {
+    const int cg = C / f.groups;
+    double s1 = sum, s2 = sumsq;
+    for (int o = 1; o < cg; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    const double n = (double)HW * cg;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const int i = b * C + c;
+    float a = rstd * f.gamma[c];
+    float bb = f.beta[c] - (float)mean * a;
+    if (f.film_mode == 1) {
+        const float sc = f.film[(size_t)b * f.film_bs + f.film_off + c] + 1.f;
+        const float sf = f.film[(size_t)b * f.film_bs + f.film_off + C + c];
+        a *= sc; bb = bb * sc + sf;
+    } else if (f.film_mode == 2) {
+        f.E[i] = f.film[(size_t)b * f.film_bs + f.film_off + c];
+    }
+    f.A[i] = a; f.Bv[i] = bb;
+}
+
 template <int BM, int BN, int TM, int TN, int NT, typename Acc>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, Acc& acc, const int* rowpix,
                                               const int* rowb, float* stage) {
@@ -471,9 +498,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
             if (t.tid < BN && t.n0 + t.tid < p.Cout && t.b0 + h < p.B) {
                 float a = 0.f, b = 0.f;
                 for (int g = 0; g < RPP; ++g) { a += red[(g * BN + t.tid) * 2]; b += red[(g * BN + t.tid) * 2 + 1]; }
-                const int slot = t.tile_y * p.tiles_x + t.tile_x;
-                float* d = p.gn_part + (((size_t)(t.b0 + h) * p.gn_slots + slot) * p.Cout + t.n0 + t.tid) * 2;
-                d[0] = a; d[1] = b;
+                if (p.gn_direct) {        // (host: Cout % 64 == 0, so the condition above holds or fails for whole waves)
+                    gn_direct_finalize(p.fin, t.b0 + h, t.n0 + t.tid, p.Cout, p.H * p.W, a, b);
+                } else {
+                    const int slot = t.tile_y * p.tiles_x + t.tile_x;
+                    float* d = p.gn_part + (((size_t)(t.b0 + h) * p.gn_slots + slot) * p.Cout + t.n0 + t.tid) * 2;
+                    d[0] = a; d[1] = b;
+                }
             }
         }
     }

@@ -232,9 +232,9 @@ int conv_splitk(const ConvArgs& a) {
 
 // out[b][p][c] = bias[c] + sum_split ws[split][b][p][c] in a fixed order; gn_part (optional): the GroupNorm partial sums of the finished
 // output in the one-slot form gn_finalize reads ([b][0][c] = (sum, sum of squares) over the sample's pixels).  The maps that take this
-// path have at most 128 pixels; Cout is a multiple of 64.
+// path have at most 128 pixels; Cout is a multiple of 64.  fin.A != nullptr: the GroupNorm affine itself instead of the partial sums.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int nsplit, size_t per_split, const float* __restrict__ bias, int HW,
-                                                            int Cout, float* __restrict__ out, float* __restrict__ gn_part) {
+                                                            int Cout, float* __restrict__ out, float* __restrict__ gn_part, GnFinArgs fin) {
     // workgroup = (sample, 64 channels); thread = (channel quad, one of sixteen pixel groups): float4 accesses, at most eight pixels per
     // thread on the 10 x 10 maps (one channel and every fourth pixel per thread ran 25 dependent rounds: 12 us per launch, 17 launches)
     __shared__ float r1[16][64], r2[16][64];
@@ -261,8 +261,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const int cl = threadIdx.x;
         float a = 0.f, q = 0.f;
         for (int g = 0; g < 16; ++g) { a += r1[g][cl]; q += r2[g][cl]; }
-        *reinterpret_cast<float2*>(gn_part + ((size_t)b * Cout + blockIdx.x * 64 + cl) * 2) = make_float2(a, q);
+        if (fin.A) gn_direct_finalize(fin, b, blockIdx.x * 64 + cl, Cout, HW, a, q);      // this workgroup saw the whole sample for its 64 channels
+        else *reinterpret_cast<float2*>(gn_part + ((size_t)b * Cout + blockIdx.x * 64 + cl) * 2) = make_float2(a, q);
     }
+}
+
+// Can this convolution's own launch(es) finalize the GroupNorm of its output (a.gn_fin) -- i.e. does one workgroup see every pixel of a
+// sample for its channels?  True for the split-K maps (the reduce kernel: workgroup = (sample, 64 channels)) and for fused-statistics
+// launches whose spatial tile covers the whole map (the 8 x 8 maps' two-images-per-tile form, and any map inside one tile); larger maps are
+// cut over several workgroups and keep the gn_finalize launch.  Ask AFTER the workspace decision (a.splitk_ws) has been made.
+static bool gn_direct_shape(const ConvArgs& a) {
+    const int C = a.cw.Cout, G = a.gn_fin.groups;
+    if (!a.gn_part || !a.gn_fin.A || G <= 0 || C % G || C % 64 || a.cw.CoutPad != C) return false;
+    const int cg = C / G;
+    return cg <= 64 && (cg & (cg - 1)) == 0;
+}
+bool conv_gn_direct(const ConvArgs& a) {
+    if (!gn_direct_shape(a) || conv_uses_winograd(a)) return false;
+    static const bool off = getenv("HICDIFF_GN_DIRECT") && atoi(getenv("HICDIFF_GN_DIRECT")) == 0;
+    if (off) return false;
+    if (a.splitk_ws && conv_splitk(a) > 1) return true;            // (launch_conv splits only when it was given a workspace)
+    const ConvPlan pl = plan_conv(a);
+    if (!gn_in_epilogue(pl)) return false;
+    return (a.H + pl.g.TH - 1) / pl.g.TH == 1 && (a.W + pl.g.TW - 1) / pl.g.TW == 1;
 }
 
 int conv_gn_slots(const ConvArgs& a) {
@@ -329,6 +350,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.gn_part = nullptr; k.gn_slots = 0;
     if (a.gn_part && gn_in_epilogue(pl)) { k.gn_part = a.gn_part; k.gn_slots = k.tiles_y * k.tiles_x; }
     if (gn_slots_out) *gn_slots_out = k.gn_slots;
+    const bool direct = conv_gn_direct(a);
+    k.gn_direct = 0; k.fin = GnFinArgs{};
+    if (direct && k.gn_part) { k.gn_direct = 1; k.fin = a.gn_fin; }
     L.lds = pl.lds; L.ck = pl.ck; L.cfg = pl.cfg;
     k.m16 = pl.fast && pl.pitch == 160;
     k.xs_stride = pl.xs_stride; k.pt_n4 = pl.pt_n4;
@@ -339,13 +363,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
         const int nch = k.Cin / pl.ck;
         k.ksplit = ks; k.kchunks = (nch + ks - 1) / ks;
         k.split_stride = (unsigned long long)a.B * a.H * a.W * k.Cout;
-        k.out = a.splitk_ws; k.bias = nullptr; k.gn_part = nullptr; k.gn_slots = 0;
+        k.out = a.splitk_ws; k.bias = nullptr; k.gn_part = nullptr; k.gn_slots = 0; k.gn_direct = 0;
         if (gn_slots_out) *gn_slots_out = a.gn_part ? 1 : 0;
         if (k.Cout != k.CoutPad) { hd_set_error("conv: split-K needs Cout a multiple of 64"); return -1; }
         const int rc = launch_conv_bf16x3(L, st);
         if (rc) return rc;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(k.Cout / 64, a.B), dim3(256), 0, st, a.splitk_ws, ks, (size_t)k.split_stride, a.cw.bias, a.H * a.W,
-                           k.Cout, a.out, a.gn_part);
+                           k.Cout, a.out, a.gn_part, direct ? a.gn_fin : GnFinArgs{});
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { hd_set_error(std::string("splitk_reduce: ") + hipGetErrorString(e)); return -3; }
         return 0;

@@ -415,13 +415,16 @@ static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* 
     float* part = nullptr;
     HD_TRY(r.alloc((size_t)a.B * slots * C * 2, &part));
     a.gn_part = fused ? part : nullptr;
-    HD_TRY(run_conv(r, a));
-    if (!fused && !r.dry) { int s2 = 0; HD_TRY(launch_gn_partial(a.out, a.B, HW, C, part, &s2, r.st)); }
     HD_TRY(r.alloc((size_t)a.B * C, A));
     HD_TRY(r.alloc((size_t)a.B * C, Bv));
     *E = nullptr;
     if (film_mode == 2) HD_TRY(r.alloc((size_t)a.B * C, E));
-    if (!r.dry)
+    // where one workgroup of the convolution (or of its split-K reduce) sees a whole sample, it writes the affine itself: no gn_finalize launch
+    a.gn_fin.gamma = gamma; a.gn_fin.beta = beta; a.gn_fin.film = r.film; a.gn_fin.film_bs = r.film_bs; a.gn_fin.film_off = film_off;
+    a.gn_fin.film_mode = film_mode; a.gn_fin.groups = r.c->arch.groups; a.gn_fin.A = *A; a.gn_fin.Bv = *Bv; a.gn_fin.E = *E;
+    HD_TRY(run_conv(r, a));
+    if (!fused && !r.dry) { int s2 = 0; HD_TRY(launch_gn_partial(a.out, a.B, HW, C, part, &s2, r.st)); }
+    if (!r.dry && !(fused && conv_gn_direct(a)))
         HD_TRY(launch_gn_finalize(part, slots, a.B, HW, C, r.c->arch.groups, gamma, beta, r.film, r.film_bs, film_off, film_mode, *A,
                                   *Bv, *E, r.st));
     r.free(part);

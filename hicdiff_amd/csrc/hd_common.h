@@ -40,6 +40,15 @@ enum EpFlags {
     EP_LN_RES = 16         // v = LayerNorm_channels(v) * ep_ln_g[n] + res[pix][n]   (LinearAttention to_out tail, src/hicdiff.py:207-210,64-70); needs Cout == tile width
 };
 
+// GroupNorm finalize folded into the producer (conv epilogue / split-K reduce) where one workgroup sees all pixels of a sample for its
+// channels: what gn_finalize_kernel would compute from the partial sums -- the per-(sample, channel) affine A, Bv [, E] -- written directly.
+// A == nullptr: not requested.
+struct GnFinArgs {
+    const float* gamma = nullptr; const float* beta = nullptr; const float* film = nullptr;
+    int film_bs = 0, film_off = 0, film_mode = 0, groups = 8;
+    float* A = nullptr; float* Bv = nullptr; float* E = nullptr;
+};
+
 struct ConvArgs {
     // input (optionally the channel concat of two tensors, never materialised)
     const float* in0 = nullptr; const float* in1 = nullptr;
@@ -66,6 +75,7 @@ struct ConvArgs {
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
     // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
     float* gn_part = nullptr;
+    GnFinArgs gn_fin;                 // with gn_part: also finalize in the kernel when it can (launch_conv reports whether it did)
     // split-K workspace (conv_splitk(a) * B*H*W*Cout floats) for the convolutions the planner splits; null: never split
     float* splitk_ws = nullptr;
     int plain_bf16 = 0;               // with precision == HD_PREC_BF16X3: drop the two correction products where a plain-bf16 variant exists (training option)
@@ -94,6 +104,7 @@ int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes
 
 // ---- launchers (each only enqueues on `st`) ---------------------------------------------------
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
+bool conv_gn_direct(const ConvArgs& a);   // with a.gn_fin set: launch_conv writes the GroupNorm affine itself (no gn_finalize launch needed)
 int conv_splitk(const ConvArgs& a);    // K splits the planner wants for this convolution (1: none); a.precision must be set
 int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials would use (0: not fusable)
 
