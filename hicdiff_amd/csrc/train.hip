@@ -853,6 +853,15 @@ __global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* __restr
     *reinterpret_cast<float4*>(a + e) = o;
 }
 
+// A[b][c] = scale + 1 (1 for SR3's additive form) in the layout of the FiLM rows, so that the second convolution's loader can apply
+// a = silu(u A + shift) while it stages u (IN_AFFINE_SILU) instead of reading a materialised copy: every block of the step in one launch.
+__global__ __launch_bounds__(256) void film_affine_kernel(const float* __restrict__ film, int film_bs, int C, size_t rows, float* __restrict__ A) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * C) return;
+    const size_t r = i / C; const int c = (int)(i % C);
+    A[r * film_bs + c] = film_bs == 2 * C ? film[r * film_bs + c] + 1.f : 1.f;
+}
+
 // g (in: dL/da * 1/gscale; out: dL/du), u: pre-FiLM conv output.  v = u (sc+1) + sh; dv = gscale * g * silu'(v);
 // du = dv (sc+1); part[(b*nchunk + chunk)][0][c] = sum dv*u (d scale), [1][c] = sum dv (d shift).
 __global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ film,
@@ -1317,6 +1326,7 @@ struct hd_trainer {
     // activations
     std::vector<float*> X, U;             // X[0..nres], U[0..nres-1]
     float *Y = nullptr, *out = nullptr, *xt = nullptr, *dout = nullptr, *g0 = nullptr, *g1 = nullptr, *g2 = nullptr, *per = nullptr;
+    float* filmA = nullptr;               // [n][B][FW]: scale + 1 at the scale columns (the second convolution's loader applies FiLM + SiLU)
     float *emb = nullptr, *h1pre = nullptr, *temb = nullptr, *film = nullptr, *dfilm = nullptr, *dst = nullptr, *dh1 = nullptr, *fpart = nullptr,
           *spart = nullptr, *mpart = nullptr;
 };
@@ -1476,6 +1486,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->per = (float*)need(dev_alloc<float>(t, 2 * B));
     t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
+    t->filmA = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));
     t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));   // sized for the wider form
     t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     const int nchunk = (S * S + 63) / 64;
@@ -1534,10 +1545,13 @@ int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long
 }  // extern "C"
 
 // ---- one training step ---------------------------------------------------------------------------------------------
-static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st) {
+// inA / inB (optional, rows of FW floats per sample): the loader applies silu(x inA + inB) while it stages x
+static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st,
+                 const float* inA = nullptr, const float* inB = nullptr) {
     ConvArgs a;
     a.in0 = in; a.C0 = tr->F; a.B = tr->B; a.H = tr->S; a.W = tr->S; a.IH = tr->S; a.IW = tr->S; a.stride = 1; a.pad = 1; a.cw = w; a.out = out;
     a.ep = ep; a.alpha = alpha; a.res = res; a.precision = HD_PREC_BF16X3; a.plain_bf16 = tr->plain;
+    if (inA) { a.in_mode = IN_AFFINE_SILU; a.inA = inA; a.inB = inB; a.in_bstride = tr->FW; }
     return launch_conv(a, st, nullptr);
 }
 
@@ -1606,14 +1620,26 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     hipLaunchKernelGGL(lin_fwd_kernel, dim3((FW + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, FW, sr3 ? 0 : 1,
                        tr->film, FW, lstride, lstride, (size_t)B * FW);
     TR_TRY(check_launch("time/film forward"));
+    // plain-bf16 arithmetic has no transforming-loader form of the 8-wave kernel: it keeps the materialised pass
+    static const bool no_film_loader = getenv("HICDIFF_TRAIN_FILM_PASS") != nullptr;
+    const bool film_in_loader = !tr->plain && !no_film_loader;
+    if (film_in_loader) {
+        const size_t rows = (size_t)n * B;
+        hipLaunchKernelGGL(film_affine_kernel, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, tr->film, FW, F, rows, tr->filmA);
+        TR_TRY(check_launch("film_affine"));
+    }
     TR_TRY(launch_conv_small_cin(tr->xt, cond, params + tr->o_head_w, params + tr->o_head_b, tr->X[0], B, S, 3, tr->cin0, F, st));
     const size_t n4 = act / 4;
     for (int i = 0; i < n; ++i) {
         const float* film = tr->film + (size_t)i * B * FW;
         TR_TRY(conv3(tr, tr->fwd[i], tr->X[i], tr->U[i], 0, 1.f, nullptr, st));
-        hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, FW, HW, F, n4, tr->g0);
-        TR_TRY(check_launch("film_silu_fwd"));
-        TR_TRY(conv3(tr, tr->fwd[i], tr->g0, tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
+        if (film_in_loader) {                 // a = silu(film(u)) is formed while the second convolution stages u: no 2 x 268 MB pass per block
+            TR_TRY(conv3(tr, tr->fwd[i], tr->U[i], tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st, tr->filmA + (size_t)i * B * FW, film + (FW - F)));
+        } else {
+            hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, FW, HW, F, n4, tr->g0);
+            TR_TRY(check_launch("film_silu_fwd"));
+            TR_TRY(conv3(tr, tr->fwd[i], tr->g0, tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
+        }
     }
     TR_TRY(conv3(tr, tr->fwd[n], tr->X[n], tr->Y, EP_RES, 1.f, tr->X[0], st));
     {

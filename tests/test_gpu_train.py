@@ -803,6 +803,57 @@ def test_gradient_stages_are_final_at_their_event(net):
     side.synchronize()
 
 
+def test_adam_state_dict_round_trip_and_torch_layout():
+    """The per-epoch checkpoint form of the pretrain scripts (pretrain/train_hicedrn_Diff.py:93-96: {'epoch', 'model_state_dict',
+    'optimizer_state_dict'}): Adam.state_dict() has torch.optim.Adam's layout (it loads into one), and a run resumed from
+    (model_state_dict, optimizer_state_dict) after two steps takes the same third step, bit for bit, as the run that never stopped."""
+    import copy
+    import io
+    from hicdiff_amd.optim import Adam
+    B, S = 2, 16
+    x0, lq = tiles(81, B, S).cuda(), tiles(82, B, S).cuda()
+    gen = torch.Generator().manual_seed(9)
+    draws = [(torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()) for _ in range(3)]
+
+    def run(d, opt, steps):
+        for t, eps in steps:
+            d.p_losses([lq, x0], t, eps).backward()
+            opt.step()
+            opt.zero_grad()
+
+    d = _diffusion("cond", 2, S)
+    d.train()
+    opt = Adam(d.parameters(), lr=1e-3)
+    assert opt.state_dict()["state"] == {}
+    run(d, opt, draws[:2])
+    buf = io.BytesIO()
+    torch.save({"epoch": 2, "model_state_dict": d.state_dict(), "optimizer_state_dict": opt.state_dict()}, buf)     # the reference's checkpoint form
+    run(d, opt, draws[2:])
+    want = {k: v.detach().clone() for k, v in d.model.named_parameters()}
+
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cuda")
+    sd = ck["optimizer_state_dict"]
+    n = len(list(d.parameters()))
+    assert sorted(sd["state"]) == list(range(n)) and sd["param_groups"][0]["params"] == list(range(n))
+    assert all(float(st["step"]) == 2.0 and st["exp_avg"].shape == p.shape for st, p in zip(sd["state"].values(), d.parameters()))
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in d.parameters()], lr=1e-3)
+    ref_opt.load_state_dict(copy.deepcopy(sd))                         # torch accepts the layout
+    assert torch.equal(ref_opt.state[ref_opt.param_groups[0]["params"][3]]["exp_avg_sq"], sd["state"][3]["exp_avg_sq"])
+
+    d2 = _diffusion("cond", 2, S)
+    d2.load_state_dict(ck["model_state_dict"])
+    d2.train()
+    opt2 = Adam(d2.parameters(), lr=5e-2)                              # lr comes back from the checkpoint
+    opt2.load_state_dict(sd)
+    assert opt2.param_groups[0]["lr"] == 1e-3
+    assert torch.equal(opt2.state_dict()["state"][5]["exp_avg"], sd["state"][5]["exp_avg"])      # readable before the first step, too
+    run(d2, opt2, draws[2:])
+    for k, v in d2.model.named_parameters():
+        assert torch.equal(v, want[k]), k
+    assert float(opt2.state_dict()["state"][0]["step"]) == 3.0
+
+
 def test_train_cli_unet(tmp_path, capsys):
     """train.py --arch unet: the full UNet (64, (1,2,4,8)) trains natively on 32x32 tiles; loss falls; checkpoints carry the Unet tag."""
     import json
