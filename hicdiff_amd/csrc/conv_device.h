@@ -33,7 +33,7 @@ struct ConvKArgs {
     int ep; const float* epScale; const float* epShift; int ep_bstride;
     float alpha; const float* res; const float* resA; const float* resB; int res_bstride;
     const float* ep_ln_g; unsigned long long w_bstride; float* ln_stats_out;
-    float* out; float* gn_part; int gn_slots;
+    float* out; float* pre_out; float* gn_part; int gn_slots;
     GnFinArgs fin; int gn_direct;   // gn_direct: the workgroup holds every pixel of its sample(s): write the GroupNorm affine (fin) instead of leaving it to gn_finalize
     int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
@@ -423,6 +423,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                         }
                     }
                     if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                        if (p.pre_out && pix >= 0) *reinterpret_cast<f32x4*>(p.pre_out + (size_t)pix * p.Cout + n) = f32x4{v[0], v[1], v[2], v[3]};
                         if (p.ep & EP_FILM_SILU) {
                             v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
                             v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;

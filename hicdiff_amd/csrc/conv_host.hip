@@ -306,7 +306,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ep = a.ep; k.epScale = a.epScale; k.epShift = a.epShift; k.ep_bstride = a.ep_bstride;
     k.alpha = a.alpha; k.res = a.res; k.resA = a.resA; k.resB = a.resB; k.res_bstride = a.res_bstride;
     k.ep_ln_g = a.ep_ln_g; k.w_bstride = a.w_bstride; k.ln_stats_out = a.ln_stats_out;
-    k.out = a.out;
+    k.out = a.out; k.pre_out = a.pre_out;
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     k.plain = a.plain_bf16;
     k.m16 = 0;
@@ -318,6 +318,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
 #endif
     // the epilogue's fast path forms 32-bit element offsets (conv_device.h)
     if ((long long)a.B * a.H * a.W * a.cw.Cout >= (1LL << 31)) { hd_set_error("conv: output tensors of 2^31 elements or more are not supported (cut the batch)"); return -1; }
+    if (a.pre_out && (!(a.ep & (EP_FILM_SILU | EP_ADD_SILU)) || a.cw.Cout % 4 || conv_uses_winograd(a) || (a.splitk_ws && conv_splitk(a) > 1))) {
+        hd_set_error("conv: pre_out rides on the FiLM / additive SiLU epilogue of an unsplit direct convolution with Cout % 4 == 0"); return -1;
+    }
     if (conv_uses_winograd(a)) {
         if (k.Cin != a.cw.Cin) { hd_set_error("conv: channel counts do not match the packed weight"); return -1; }
         k.tiles_y = a.H / 16; k.tiles_x = a.W / 16; k.ntiles_n = k.CoutPad / 64;

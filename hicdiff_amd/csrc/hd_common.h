@@ -72,6 +72,7 @@ struct ConvArgs {
     float* ln_stats_out = nullptr;    // EP_LN_STATS: [pixels][2]
     size_t w_bstride = 0;             // bf16x3 only: bytes between per-sample images of cw.wsplit (0: one shared weight); forces one sample per tile
     float* out = nullptr;
+    float* pre_out = nullptr;         // EP_FILM_SILU / EP_ADD_SILU: also store the value BEFORE the FiLM + SiLU (bias added) here -- the training step keeps both
     // optional per-channel partial sums of the (pre-activation) output for GroupNorm:
     // gn_part[b][slot][Cout][2]; slots per sample = gn_slots (filled by the launcher)
     float* gn_part = nullptr;

@@ -853,15 +853,6 @@ __global__ __launch_bounds__(256) void film_silu_fwd_kernel(const float* __restr
     *reinterpret_cast<float4*>(a + e) = o;
 }
 
-// A[b][c] = scale + 1 (1 for SR3's additive form) in the layout of the FiLM rows, so that the second convolution's loader can apply
-// a = silu(u A + shift) while it stages u (IN_AFFINE_SILU) instead of reading a materialised copy: every block of the step in one launch.
-__global__ __launch_bounds__(256) void film_affine_kernel(const float* __restrict__ film, int film_bs, int C, size_t rows, float* __restrict__ A) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * C) return;
-    const size_t r = i / C; const int c = (int)(i % C);
-    A[r * film_bs + c] = film_bs == 2 * C ? film[r * film_bs + c] + 1.f : 1.f;
-}
-
 // g (in: dL/da * 1/gscale; out: dL/du), u: pre-FiLM conv output.  v = u (sc+1) + sh; dv = gscale * g * silu'(v);
 // du = dv (sc+1); part[(b*nchunk + chunk)][0][c] = sum dv*u (d scale), [1][c] = sum dv (d shift).
 __global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ film,
@@ -1324,9 +1315,8 @@ struct hd_trainer {
     Wgrad wg;                             // operand images + partials of the 256 -> 256 weight gradients
     float *colpart = nullptr, *ctmp = nullptr;
     // activations
-    std::vector<float*> X, U;             // X[0..nres], U[0..nres-1]
+    std::vector<float*> X, U, Aact;       // X[0..nres], U[0..nres-1]; Aact[i] = silu(film(U[i])) (288 GB of HBM: keeping it is cheaper than forming it twice more)
     float *Y = nullptr, *out = nullptr, *xt = nullptr, *dout = nullptr, *g0 = nullptr, *g1 = nullptr, *g2 = nullptr, *per = nullptr;
-    float* filmA = nullptr;               // [n][B][FW]: scale + 1 at the scale columns (the second convolution's loader applies FiLM + SiLU)
     float *emb = nullptr, *h1pre = nullptr, *temb = nullptr, *film = nullptr, *dfilm = nullptr, *dst = nullptr, *dh1 = nullptr, *fpart = nullptr,
           *spart = nullptr, *mpart = nullptr;
 };
@@ -1477,23 +1467,23 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->colpart = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
     t->ctmp = (float*)need(dev_alloc<float>(t, (size_t)B * S * F));
     const size_t act = (size_t)B * S * S * F, pix = (size_t)B * S * S;
-    t->X.resize(n + 1); t->U.resize(n);
+    t->X.resize(n + 1); t->U.resize(n); t->Aact.resize(n);
     for (int i = 0; i <= n && ok; ++i) t->X[i] = (float*)need(dev_alloc<float>(t, act));
     for (int i = 0; i < n && ok; ++i) t->U[i] = (float*)need(dev_alloc<float>(t, act));
+    for (int i = 0; i < n && ok; ++i) t->Aact[i] = (float*)need(dev_alloc<float>(t, act));
     t->Y = (float*)need(dev_alloc<float>(t, act));
     t->g0 = (float*)need(dev_alloc<float>(t, act)); t->g1 = (float*)need(dev_alloc<float>(t, act)); t->g2 = (float*)need(dev_alloc<float>(t, act));
     t->out = (float*)need(dev_alloc<float>(t, pix)); t->xt = (float*)need(dev_alloc<float>(t, pix)); t->dout = (float*)need(dev_alloc<float>(t, pix));
     t->per = (float*)need(dev_alloc<float>(t, 2 * B));
     t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
-    t->filmA = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));
     t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));   // sized for the wider form
     t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     const int nchunk = (S * S + 63) / 64;
     t->fpart = (float*)need(dev_alloc<float>(t, (size_t)B * nchunk * 2 * F));
     t->spart = (float*)need(dev_alloc<float>(t, (size_t)B * ((S + 7) / 8) * F * 18));
     t->mpart = (float*)need(dev_alloc<float>(t, (size_t)n * B * t->tdim));
-    if (!ok || !stage_events(t)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 2 per block)"); }
+    if (!ok || !stage_events(t)) { hd_train_destroy(t); return tfail(nullptr, HD_ENOMEM, "hipMalloc failed while sizing the trainer (saved activations: 3 per block)"); }
     *out = t;
     return HD_OK;
 }
@@ -1545,13 +1535,10 @@ int hd_train_param_slot(const hd_trainer* t, int i, const char** name, long long
 }  // extern "C"
 
 // ---- one training step ---------------------------------------------------------------------------------------------
-// inA / inB (optional, rows of FW floats per sample): the loader applies silu(x inA + inB) while it stages x
-static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st,
-                 const float* inA = nullptr, const float* inB = nullptr) {
+static int conv3(hd_trainer* tr, const ConvW& w, const float* in, float* out, int ep, float alpha, const float* res, hipStream_t st) {
     ConvArgs a;
     a.in0 = in; a.C0 = tr->F; a.B = tr->B; a.H = tr->S; a.W = tr->S; a.IH = tr->S; a.IW = tr->S; a.stride = 1; a.pad = 1; a.cw = w; a.out = out;
     a.ep = ep; a.alpha = alpha; a.res = res; a.precision = HD_PREC_BF16X3; a.plain_bf16 = tr->plain;
-    if (inA) { a.in_mode = IN_AFFINE_SILU; a.inA = inA; a.inB = inB; a.in_bstride = tr->FW; }
     return launch_conv(a, st, nullptr);
 }
 
@@ -1620,26 +1607,26 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     hipLaunchKernelGGL(lin_fwd_kernel, dim3((FW + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, FW, sr3 ? 0 : 1,
                        tr->film, FW, lstride, lstride, (size_t)B * FW);
     TR_TRY(check_launch("time/film forward"));
-    // plain-bf16 arithmetic has no transforming-loader form of the 8-wave kernel: it keeps the materialised pass
-    static const bool no_film_loader = getenv("HICDIFF_TRAIN_FILM_PASS") != nullptr;
-    const bool film_in_loader = !tr->plain && !no_film_loader;
-    if (film_in_loader) {
-        const size_t rows = (size_t)n * B;
-        hipLaunchKernelGGL(film_affine_kernel, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, st, tr->film, FW, F, rows, tr->filmA);
-        TR_TRY(check_launch("film_affine"));
-    }
+    static const bool film_pass = getenv("HICDIFF_TRAIN_FILM_PASS") != nullptr;      // A/B: the separate FiLM + SiLU pass of round 2
+    const bool film_in_epilogue = !film_pass;
     TR_TRY(launch_conv_small_cin(tr->xt, cond, params + tr->o_head_w, params + tr->o_head_b, tr->X[0], B, S, 3, tr->cin0, F, st));
     const size_t n4 = act / 4;
     for (int i = 0; i < n; ++i) {
         const float* film = tr->film + (size_t)i * B * FW;
-        TR_TRY(conv3(tr, tr->fwd[i], tr->X[i], tr->U[i], 0, 1.f, nullptr, st));
-        if (film_in_loader) {                 // a = silu(film(u)) is formed while the second convolution stages u: no 2 x 268 MB pass per block
-            TR_TRY(conv3(tr, tr->fwd[i], tr->U[i], tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st, tr->filmA + (size_t)i * B * FW, film + (FW - F)));
+        if (film_in_epilogue) {
+            // the first convolution's epilogue writes u (kept for the backward pass) AND a = silu(film(u)): the second convolution, and later the
+            // weight gradient of its use, read a as it is (a transforming loader cost 14 % of a convolution, a separate pass 2 x 268 MB)
+            ConvArgs c1;
+            c1.in0 = tr->X[i]; c1.C0 = F; c1.B = B; c1.H = S; c1.W = S; c1.IH = S; c1.IW = S; c1.stride = 1; c1.pad = 1; c1.cw = tr->fwd[i];
+            c1.out = tr->Aact[i]; c1.pre_out = tr->U[i]; c1.precision = HD_PREC_BF16X3; c1.plain_bf16 = tr->plain;
+            c1.ep = FW > F ? EP_FILM_SILU : EP_ADD_SILU; c1.epScale = film; c1.epShift = film + (FW - F); c1.ep_bstride = FW;
+            TR_TRY(launch_conv(c1, st, nullptr));
         } else {
-            hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, FW, HW, F, n4, tr->g0);
+            TR_TRY(conv3(tr, tr->fwd[i], tr->X[i], tr->U[i], 0, 1.f, nullptr, st));
+            hipLaunchKernelGGL(film_silu_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, tr->U[i], film, FW, HW, F, n4, tr->Aact[i]);
             TR_TRY(check_launch("film_silu_fwd"));
-            TR_TRY(conv3(tr, tr->fwd[i], tr->g0, tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
         }
+        TR_TRY(conv3(tr, tr->fwd[i], tr->Aact[i], tr->X[i + 1], EP_RES, 0.1f, tr->X[i], st));
     }
     TR_TRY(conv3(tr, tr->fwd[n], tr->X[n], tr->Y, EP_RES, 1.f, tr->X[0], st));
     {
@@ -1682,10 +1669,10 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         float* dW = grads + tr->o_conv_w[i];
         float* db = grads + tr->o_conv_b[i];
         // second use of the conv: y = 0.1 conv(a) + x
-        if (direct) {                                                            // a = silu(u (scale + 1) + shift), recomputed in the loader (FW == F: shift only)
-            TR_TRY(tr->wg.run_direct(tr->U[i], F, nullptr, 0, dx, F, 3, dW, db, st, FW > F ? film : nullptr, film + (FW - F), nullptr, 0, 0.1f, false, FW, 1.f));
+        if (direct) {                                                            // a = silu(u (scale + 1) + shift) (FW == F: shift only)
+            TR_TRY(tr->wg.run_direct(tr->Aact[i], F, nullptr, 0, dx, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 0.1f, false));
         } else {
-            TR_TRY(prep(tr, tr->U[i], false, 1, film, nullptr, st));                 // a = silu(film(u)), recomputed
+            TR_TRY(prep(tr, tr->Aact[i], false, 0, nullptr, nullptr, st));           // a = silu(film(u)), kept by the forward pass
             TR_TRY(prep(tr, dx, true, 0, nullptr, tr->colpart, st));
             TR_TRY(wgrad(tr, 0.1f, false, dW, st));
             TR_TRY(colsum(tr, 0.1f, false, db, st));
