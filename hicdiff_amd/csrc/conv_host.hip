@@ -142,7 +142,8 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     const int ntaps = a.cw.KH * a.cw.KW;
     const bool ln = a.in_mode == IN_LAYERNORM || a.in_mode == IN_SOFTMAX32;   // loaders that exist in the any-filter kernels only
     const bool taps9 = a.cw.KH == 3 && a.cw.KW == 3 && !ln;      // kernels with unrolled taps
-    if (pl.fast && !wide && a.H * a.W >= 1024 && (taps9 || ntaps == 1)) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
+    static const int cfg2_min_hw = getenv("HICDIFF_CFG2_MINHW") ? atoi(getenv("HICDIFF_CFG2_MINHW")) : 1024;
+    if (pl.fast && !wide && a.H * a.W >= cfg2_min_hw && (taps9 || ntaps == 1)) { pl.BM = 256; pl.WM = 4; pl.cfg = 2; }
     // 256 x 128 tile with 8 waves (4 x 2), one workgroup per CU: the two wave groups share every weight slab
     // (half the L2 -> LDS weight traffic of the K-heavy layers) and the activation window is double-buffered.
     static const bool big = !(getenv("HICDIFF_NO_CFG3"));
