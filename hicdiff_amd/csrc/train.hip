@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_direct_kernel(WgdArgs a) {
 // row taps are three transposed reads of the same ring, and each activation is loaded from memory ONCE per workgroup: 49 KB per
 // 108 MFMAs of each of 8 waves.  Column taps, fragment reads, splitting, bias sums and the partial layout are wgrad_direct_kernel's.
 // AFF as there (0 / 1 / 2).  Layers with more than 64 input channels, 3 x 3 filters, plain source addressing.
-template <int AFF>
+// PLAIN: one bf16 MFMA per product (the optional bf16 training arithmetic): no lo images, a third of the MFMAs.
+template <int AFF, bool PLAIN = false>
 __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
     constexpr int PX = 256, PG = 64 * 2 + 64;                                    // bytes per position: 128 channels (swizzled) / 64 channels + pad
     extern __shared__ __attribute__((aligned(16))) char smem9[];
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
             uint2 lo; const uint2 hi = split_quad(xq4, lo);
             const int o = (pos & RM) * PX + ((xq * 8) ^ ((pos & 3) << 6));
             *reinterpret_cast<uint2*>(XHI + o) = hi;
-            *reinterpret_cast<uint2*>(XLO + o) = lo;
+            if constexpr (!PLAIN) *reinterpret_cast<uint2*>(XLO + o) = lo;
         }
     };
     auto g_request = [&](int k0) {
@@ -674,14 +675,14 @@ __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
             uint2 lo; const uint2 hi = split_quad(g4, lo);
             const int o = (gp0 + 32 * j + 1) * PG + gq * 8;
             *reinterpret_cast<uint2*>(GHI + o) = hi;
-            *reinterpret_cast<uint2*>(GLO + o) = lo;
+            if constexpr (!PLAIN) *reinterpret_cast<uint2*>(GLO + o) = lo;
         }
         if (tid < 32) {
             const float4 g4 = (vmask >> 6) & 1 ? rGh : zero4;
             uint2 lo; const uint2 hi = split_quad(g4, lo);
             const int o = (tid < 16 ? 0 : 65) * PG + gq * 8;
             *reinterpret_cast<uint2*>(GHI + o) = hi;
-            *reinterpret_cast<uint2*>(GLO + o) = lo;
+            if constexpr (!PLAIN) *reinterpret_cast<uint2*>(GLO + o) = lo;
         }
     };
 
@@ -738,18 +739,24 @@ __global__ __launch_bounds__(512) void wgrad_direct9_kernel(WgdArgs a, int R) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {                                     // kx = dx: G[k + 1 - kx]
                 bh[dx] = tr_read8(GHI + goff + ks * 16 * PG + (1 - dx) * PG, 4 * PG);
-                bl[dx] = tr_read8(GLO + goff + ks * 16 * PG + (1 - dx) * PG, 4 * PG);
+                if constexpr (!PLAIN) bl[dx] = tr_read8(GLO + goff + ks * 16 * PG + (1 - dx) * PG, 4 * PG);
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {                                     // ky = dy: X[k + (ky - 1) Wp], two 4-position blocks
                 const int p0 = k0 + (dy - 1) * Wp + ks * 16 + prow, p1 = p0 + 4;
                 const int o0 = (p0 & RM) * PX + (xchb ^ ((p0 & 3) << 6)), o1 = (p1 & RM) * PX + (xchb ^ ((p1 & 3) << 6));
-                const bf16x8 ah = tr_read8(XHI + o0, o1 - o0), al = tr_read8(XLO + o0, o1 - o0);
+                const bf16x8 ah = tr_read8(XHI + o0, o1 - o0);
+                if constexpr (PLAIN) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[dx], acc[dy][dx], 0, 0, 0);
-                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[dx], acc[dy][dx], 0, 0, 0);
-                    acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[dx], acc[dy][dx], 0, 0, 0);
+                    for (int dx = 0; dx < 3; ++dx) acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[dx], acc[dy][dx], 0, 0, 0);
+                } else {
+                    const bf16x8 al = tr_read8(XLO + o0, o1 - o0);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[dx], acc[dy][dx], 0, 0, 0);
+                        acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[dx], acc[dy][dx], 0, 0, 0);
+                        acc[dy][dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[dx], acc[dy][dx], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1165,10 +1172,11 @@ struct Wgrad {
     // affA / affB (/ affE), all [B][C0 + C1] or null: the input is silu(x affA + affB) (+ affE) per (sample, channel)
     int run_direct(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, int KT, float* dW, float* db, hipStream_t st,
                    const float* affA = nullptr, const float* affB = nullptr, const float* affE = nullptr, int src_mode = 0, float scale = 1.f,
-                   bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f) const {
+                   bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f, bool plain = false) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         const int Cin = C0 + C1;
-        if (direct9_ok(Cin, W, KT, src_mode, false)) return run_direct9(x0, C0, x1, C1, g, Cout, dW, db, st, affA, affB, affE, scale, accumulate, aff_bs, aff_addA);
+        if (direct9_ok(Cin, W, KT, src_mode)) return run_direct9(x0, C0, x1, C1, g, Cout, dW, db, st, affA, affB, affE, scale, accumulate, aff_bs, aff_addA, plain);
+        if (plain) { hd_set_error("wgrad (direct): the plain-bf16 form exists in the nine-tap kernel only"); return -1; }
         const bool m64 = Cin <= 64;
         const bool aff = affA || affB;
         const int BMh = m64 ? 64 : 128, Mt = (Cin + BMh - 1) / BMh, Nt = Cout / 64, Mpad = Mt * BMh;
@@ -1208,12 +1216,13 @@ struct Wgrad {
         return check_launch("wg_reduce");
     }
     // the nine-tap form (wgrad_direct9_kernel: one 8-wave workgroup per CU, activations loaded once): 3 x 3, more than 64 input channels
-    static bool direct9_ok(int Cin, int W, int KT, int src_mode, bool plain) {
+    static bool direct9_ok(int Cin, int W, int KT, int src_mode) {
         static const bool off = getenv("HICDIFF_WG_NO9") != nullptr;
-        return !off && KT == 3 && !src_mode && !plain && Cin > 64 && 2 * (W + 1) <= 192;
+        return !off && KT == 3 && !src_mode && Cin > 64 && 2 * (W + 1) <= 192;
     }
     int run_direct9(const float* x0, int C0, const float* x1, int C1, const float* g, int Cout, float* dW, float* db, hipStream_t st, const float* affA = nullptr,
-                    const float* affB = nullptr, const float* affE = nullptr, float scale = 1.f, bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f) const {
+                    const float* affB = nullptr, const float* affE = nullptr, float scale = 1.f, bool accumulate = false, int aff_bs = 0, float aff_addA = 0.f,
+                    bool plain = false) const {
         static const int xcd_group = getenv("HICDIFF_WG_NOXCD") ? 0 : 1;
         static const int want = getenv("HICDIFF_WG9_TARGET") ? atoi(getenv("HICDIFF_WG9_TARGET")) : 256;
         const int Cin = C0 + C1, KT = 3;
@@ -1235,15 +1244,16 @@ struct Wgrad {
         a.partial = partial; a.biaspart = db ? partial + (size_t)eff * per_split_floats : nullptr; a.xcd_group = xcd_group;
         a.affA = affA; a.affB = affB; a.affE = affE; a.aff_bs = aff_bs > 0 ? aff_bs : Cin; a.aff_addA = aff_addA; a.src_mode = 0;
         const size_t lds = (size_t)R * 256 * 2 + (size_t)66 * 192 * 2;
-        hd_prof_begin("wgrad_direct9_kernel", 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
+        hd_prof_begin(plain ? "wgrad_direct9_kernel<plain bf16>" : "wgrad_direct9_kernel", 2.0 * KT * KT * Cin * Cout * (double)B * H * W, 4.0 * (Cin + Cout) * (double)B * H * W + 4.0 * eff * KT * KT * Cin * Cout, st);
         const dim3 grid(Mt * Nt * eff);
-#define HD_W9(AFF_)                                                                                                          \
+#define HD_W9(AFF_, PL_)                                                                                                     \
         do {                                                                                                                 \
             static bool attr = false;                                                                                        \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_direct9_kernel<AFF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
-            hipLaunchKernelGGL((wgrad_direct9_kernel<AFF_>), grid, dim3(512), lds, st, a, R);                                \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)wgrad_direct9_kernel<AFF_, PL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+            hipLaunchKernelGGL((wgrad_direct9_kernel<AFF_, PL_>), grid, dim3(512), lds, st, a, R);                           \
         } while (0)
-        if (aff && affE) HD_W9(2); else if (aff) HD_W9(1); else HD_W9(0);
+        if (plain) { if (aff && affE) HD_W9(2, true); else if (aff) HD_W9(1, true); else HD_W9(0, true); }
+        else if (aff && affE) HD_W9(2, false); else if (aff) HD_W9(1, false); else HD_W9(0, false);
 #undef HD_W9
         conv_prof_end(st);
         if (check_launch("wgrad direct9")) return -3;
@@ -1651,9 +1661,10 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     // body_tail: dX_n = dgrad(dY); dW = wgrad(X_n, dY); the skip r sends dY to the head output as well
     // weight gradients: straight from the NHWC tensors (wgrad_direct_kernel) in the default arithmetic; operand rewrite + GEMM for plain bf16
     static const bool no_direct = getenv("HICDIFF_WG_NODIRECT") != nullptr;
-    const bool direct = !tr->plain && !no_direct;
+    const bool plain = tr->plain != 0;
+    const bool direct = !no_direct && (!plain || Wgrad::direct9_ok(F, S, 3, 0));     // the plain-bf16 arithmetic has the nine-tap direct kernel only
     if (direct) {
-        TR_TRY(tr->wg.run_direct(tr->X[n], F, nullptr, 0, dY, F, 3, grads + tr->o_conv_w[n], grads + tr->o_conv_b[n], st));
+        TR_TRY(tr->wg.run_direct(tr->X[n], F, nullptr, 0, dY, F, 3, grads + tr->o_conv_w[n], grads + tr->o_conv_b[n], st, nullptr, nullptr, nullptr, 0, 1.f, false, 0, 0.f, plain));
     } else {
         TR_TRY(prep(tr, tr->X[n], false, 0, nullptr, nullptr, st));
         TR_TRY(prep(tr, dY, true, 0, nullptr, tr->colpart, st));
@@ -1670,7 +1681,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         float* db = grads + tr->o_conv_b[i];
         // second use of the conv: y = 0.1 conv(a) + x
         if (direct) {                                                            // a = silu(u (scale + 1) + shift) (FW == F: shift only)
-            TR_TRY(tr->wg.run_direct(tr->Aact[i], F, nullptr, 0, dx, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 0.1f, false));
+            TR_TRY(tr->wg.run_direct(tr->Aact[i], F, nullptr, 0, dx, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 0.1f, false, 0, 0.f, plain));
         } else {
             TR_TRY(prep(tr, tr->Aact[i], false, 0, nullptr, nullptr, st));           // a = silu(film(u)), kept by the forward pass
             TR_TRY(prep(tr, dx, true, 0, nullptr, tr->colpart, st));
@@ -1683,7 +1694,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         TR_TRY(check_launch("film_silu_bwd"));
         // first use: u = conv(x)
         if (direct) {
-            TR_TRY(tr->wg.run_direct(tr->X[i], F, nullptr, 0, da, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 1.f, true));
+            TR_TRY(tr->wg.run_direct(tr->X[i], F, nullptr, 0, da, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 1.f, true, 0, 0.f, plain));
         } else {
             TR_TRY(prep(tr, tr->X[i], false, 0, nullptr, nullptr, st));
             TR_TRY(prep(tr, da, true, 0, nullptr, tr->colpart, st));
