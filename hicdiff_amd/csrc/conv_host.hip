@@ -128,11 +128,11 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     // Feature maps smaller than 8x8 (the 5x5 level of 40x40 tiles) take 64-wide N tiles even for wide outputs: a handful of
     // M tiles with K in the thousands needs more workgroups, not bigger ones (unet40, 64 tiles: 4.54 -> 3.73 ms/step; measured
     // a loss from 8x8 upwards at 256 tiles).  By the map size only -- never by the batch.
-    // Round 3: the 10x10 level of the 40x40 tiles as well (4 tiles: 2.11 -> 2.01 ms/step, 64 tiles: 2.77 = 2.77) -- but not the 8x8 maps
-    // (64 pixels) that only the 64x64 workloads have, where the 256-tile measurement above stands.
-    static const int narrow_max_hw = getenv("HICDIFF_NARROW_MAXHW") ? atoi(getenv("HICDIFF_NARROW_MAXHW")) : 0;
-    const int hw = a.H * a.W;
-    const bool narrow_map = a.narrow_max_hw > 0 ? hw <= a.narrow_max_hw : narrow_max_hw > 0 ? hw <= narrow_max_hw : (hw <= 100 && hw != 64);
+    // Round 3: narrow tiles on the 10x10 level as well measured 2.11 -> 2.01 ms/step at 4 tiles of 40x40 (64 tiles: 2.77 = 2.77) and were NOT
+    // adopted: the tile width sets the order of the epilogue's GroupNorm sums, and the exact-fp32 DDIM golden chain (eta = 0, 20 steps; it
+    // amplifies last-bit differences a thousandfold) moved from inside to just outside its 1e-3 bound (1.17e-3).  HICDIFF_NARROW_MAXHW overrides.
+    static const int narrow_max_hw = getenv("HICDIFF_NARROW_MAXHW") ? atoi(getenv("HICDIFF_NARROW_MAXHW")) : 63;
+    const bool narrow_map = a.H * a.W <= (a.narrow_max_hw > 0 ? a.narrow_max_hw : narrow_max_hw);
     const bool wide = a.cw.CoutPad % 128 == 0 && !narrow_map;
     pl.BN = wide ? 128 : 64;
     pl.BM = 128; pl.WM = 2; pl.cfg = wide ? 0 : 1;
