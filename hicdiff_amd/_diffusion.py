@@ -134,7 +134,7 @@ class DiffusionCore(nn.Module):
         self.tile_offset = 0         # global index of this rank's first tile (sharded sampling)
 
     _HOST_KEYS = ("alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1",
-                  "posterior_mean_coef2", "posterior_log_variance_clipped")
+                  "posterior_mean_coef2", "posterior_log_variance_clipped", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")
 
     @property
     def _host(self):
@@ -205,11 +205,20 @@ class DiffusionCore(nn.Module):
         return mean, var, logvar, x_start
 
     # -- fused reverse step ----------------------------------------------------------------------
+    def _x0_coefs(self, t_idx: int):
+        """(f1, f2) with x0 = f1 x - f2 out, the form the fused update kernel evaluates (hd_ddpm_coef's first two fields): what the network
+        predicts is the noise (predict_start_from_noise, src/hicdiff.py:529-533), x0 itself, or v (predict_start_from_v, :548-552)."""
+        h = self._host
+        if self.objective == "pred_noise":
+            return float(h["sqrt_recip_alphas_cumprod"][t_idx]), float(h["sqrt_recipm1_alphas_cumprod"][t_idx])
+        if self.objective == "pred_x0":
+            return 0.0, -1.0
+        return float(h["sqrt_alphas_cumprod"][t_idx]), float(h["sqrt_one_minus_alphas_cumprod"][t_idx])
+
     def _coef(self, t_idx: int) -> L.HdDdpmCoef:
         h = self._host
         c = L.HdDdpmCoef()
-        c.sqrt_recip_alphas_cumprod = float(h["sqrt_recip_alphas_cumprod"][t_idx])
-        c.sqrt_recipm1_alphas_cumprod = float(h["sqrt_recipm1_alphas_cumprod"][t_idx])
+        c.sqrt_recip_alphas_cumprod, c.sqrt_recipm1_alphas_cumprod = self._x0_coefs(t_idx)
         c.posterior_mean_coef1 = float(h["posterior_mean_coef1"][t_idx])
         c.posterior_mean_coef2 = float(h["posterior_mean_coef2"][t_idx])
         c.sigma = float(h["sigma"][t_idx]) if t_idx > 0 else 0.0
@@ -220,9 +229,8 @@ class DiffusionCore(nn.Module):
         return c
 
     def _step_inplace(self, img, t_idx: int, cond, x0_out=None):
-        """img <- p_sample(img, t): one hd_ddpm_step call (eps-net + clamp + posterior + noise)."""
-        if self.objective != "pred_noise":
-            raise NotImplementedError("the fused sampler implements objective='pred_noise' (the only one the reference drivers use)")
+        """img <- p_sample(img, t): one hd_ddpm_step call (eps-net + clamp + posterior + noise).  The three objectives differ only in the two
+        coefficients that turn the network's output into x0 (_x0_coefs)."""
         eng = self.model.engine(img.device)
         noise = None
         if t_idx > 0 and self.noise_source is not None:
@@ -284,8 +292,6 @@ class DiffusionCore(nn.Module):
         replay with device noise) with other coefficients: x <- sqrt(a_next) x0 + sqrt(1 - a_next - sigma^2) eps + sigma z."""
         shape = tuple(shape)
         device, T, S, eta = self._device(), self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
-        if self.objective != "pred_noise":
-            raise NotImplementedError("the fused sampler implements objective='pred_noise' (the only one the reference drivers use)")
         times = list(reversed(torch.linspace(-1, T - 1, steps=S + 1).int().tolist()))
         h = self._host
         ac = h["alphas_cumprod"]
@@ -294,8 +300,7 @@ class DiffusionCore(nn.Module):
         imgs = [img.clone()] if return_all_timesteps else None
         for time, time_next in zip(times[:-1], times[1:]):
             c = L.HdDdpmCoef()
-            c.sqrt_recip_alphas_cumprod = float(h["sqrt_recip_alphas_cumprod"][time])
-            c.sqrt_recipm1_alphas_cumprod = float(h["sqrt_recipm1_alphas_cumprod"][time])
+            c.sqrt_recip_alphas_cumprod, c.sqrt_recipm1_alphas_cumprod = self._x0_coefs(time)
             c.time_value = float(time)
             c.posterior_mean_coef2 = 0.0
             noise = None
@@ -305,6 +310,11 @@ class DiffusionCore(nn.Module):
                 a, an = ac[time], ac[time_next]
                 sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
                 c.posterior_mean_coef1, c.eps_coef, c.sigma = float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
+                if self.objective != "pred_noise":
+                    # the noise is derived from the CLIPPED x0 (model_predictions, src/hicdiff.py:571-580): eps = (R x - x0) / Rm1, so
+                    # sqrt(a_next) x0 + k eps = (sqrt(a_next) - k / Rm1) x0 + (k R / Rm1) x -- the kernel's x0 and x terms, no output term
+                    R, Rm1, k = float(h["sqrt_recip_alphas_cumprod"][time]), float(h["sqrt_recipm1_alphas_cumprod"][time]), c.eps_coef
+                    c.posterior_mean_coef1, c.posterior_mean_coef2, c.eps_coef = c.posterior_mean_coef1 - k / Rm1, k * R / Rm1, 0.0
                 if self.noise_source is not None:      # the reference draws randn_like(img) at every such step, eta = 0 included
                     noise = self.noise_source.randn(shape).contiguous()
             eng.ddpm_step(img, None, noise, c, None, seed=self.seed, tile_offset=self.tile_offset, step=time)

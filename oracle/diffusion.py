@@ -103,9 +103,10 @@ class DiffusionRef:
 
     def __init__(self, model: Callable, *, image_size: int, timesteps: int = 1000, beta_schedule: str = "sigmoid",
                  loss_type: str = "l1", kind: str = "uncond", sampling_timesteps: Optional[int] = None,
-                 ddim_sampling_eta: float = 0.0, channels: int = 1):
+                 ddim_sampling_eta: float = 0.0, channels: int = 1, objective: str = "pred_noise"):
         assert kind in ("uncond", "cond", "sr3")
-        self.model, self.kind = model, kind
+        assert objective in ("pred_noise", "pred_x0", "pred_v")        # src/hicdiff.py:461
+        self.model, self.kind, self.objective = model, kind, objective
         self.image_size, self.T, self.loss_type, self.channels = image_size, timesteps, loss_type, channels
         self.buf = diffusion_buffers(beta_schedule, timesteps)
         self.sampling_timesteps = sampling_timesteps or timesteps
@@ -125,12 +126,22 @@ class DiffusionRef:
             return self.model(x, level, cond)
         return self.model(x, torch.full((n,), t_idx, dtype=torch.long), cond)
 
+    def x0_from_output(self, x, t_idx: int, out):
+        """model_predictions, src/hicdiff.py:562-582: what the network predicts is the noise, x0 itself, or v
+        (predict_start_from_v, :548-552: x0 = sqrt_ac[t] x - sqrt(1 - ac[t]) v)."""
+        b = self.buf
+        if self.objective == "pred_noise":
+            return self.predict_x0(x, t_idx, out)
+        if self.objective == "pred_x0":
+            return out
+        return b["sqrt_alphas_cumprod"][t_idx] * x - b["sqrt_one_minus_alphas_cumprod"][t_idx] * out
+
     def p_sample(self, x, t_idx: int, cond, noise):
         """p_mean_variance + p_sample, src/hicdiff.py:584-601: clamp x0 to [-1,1], posterior mean,
         x_{t-1} = mean + exp(0.5 logvar) * z (z = 0 at t = 0)."""
         b = self.buf
-        eps = self.eps_at(x, t_idx, cond)
-        x0 = self.predict_x0(x, t_idx, eps).clamp(-1.0, 1.0)
+        eps = self.eps_at(x, t_idx, cond)                      # (the network's output: the noise only under objective 'pred_noise')
+        x0 = self.x0_from_output(x, t_idx, eps).clamp(-1.0, 1.0)
         mean = b["posterior_mean_coef1"][t_idx] * x0 + b["posterior_mean_coef2"][t_idx] * x
         if t_idx > 0:
             return mean + (0.5 * b["posterior_log_variance_clipped"][t_idx]).exp() * noise, x0, eps
@@ -159,7 +170,10 @@ class DiffusionRef:
         img = noise.randn(shape)
         for time, time_next in zip(times[:-1], times[1:]):
             eps = self.eps_at(img, time, None)
-            x0 = self.predict_x0(img, time, eps).clamp(-1.0, 1.0)
+            x0 = self.x0_from_output(img, time, eps).clamp(-1.0, 1.0)
+            if self.objective != "pred_noise":                 # predict_noise_from_start on the clipped x0 (src/hicdiff.py:571-580,535-539)
+                b = self.buf
+                eps = (b["sqrt_recip_alphas_cumprod"][time] * img - x0) / b["sqrt_recipm1_alphas_cumprod"][time]
             if time_next < 0:
                 img = x0
                 continue
@@ -180,7 +194,13 @@ class DiffusionRef:
         times p2 weight (== 1), mean over batch."""
         x = self.q_sample(x0, t, eps)
         out = self.model(x, t, cond)
-        per = (out - eps).abs() if self.loss_type == "l1" else (out - eps) ** 2
+        b = self.buf
+        target = eps                                           # src/hicdiff.py:733-741
+        if self.objective == "pred_x0":
+            target = x0
+        elif self.objective == "pred_v":                       # predict_v, :542-546
+            target = _col(b["sqrt_alphas_cumprod"], t) * eps - _col(b["sqrt_one_minus_alphas_cumprod"], t) * x0
+        per = (out - target).abs() if self.loss_type == "l1" else (out - target) ** 2
         per = per.reshape(per.shape[0], -1).mean(dim=1) * self.buf["p2_loss_weight"].gather(-1, t)
         return per.mean()
 

@@ -305,6 +305,42 @@ def case_trajectories():
     save("trajectories", **out)
 
 
+def case_objectives():
+    """objective = 'pred_x0' / 'pred_v' (src/hicdiff.py:441,461,566-580,733-741; no reference driver sets them): a 20-step ancestral chain
+    and a loss value each, same network weights read as an x0- / v-predictor."""
+    out = {}
+    T, B, S = 20, 2, 40
+    m, cfg = build_unet("uncond")
+    x0 = tiles(5, B, S)
+    t = torch.tensor([3, 17])
+    eps = gauss(6, x0.shape)
+    out["x0"], out["t"], out["eps"] = x0, t, eps
+    for obj in ("pred_x0", "pred_v"):
+        d = R0.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear", objective=obj)
+        torch.manual_seed(4242)
+        stack = d.sample(torch.zeros(B, 1, S, S), return_all_timesteps=True)
+        oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", objective=obj)
+        final, kept = oref.p_sample_loop((B, 1, S, S), OD.TorchNoise(4242), keep_every=5)
+        for k in range(0, T, 5):
+            out[f"{obj}_x_after_t{k}"] = stack[:, T - k]
+            check(f"{obj} chain x after t={k}", stack[:, T - k], kept[k], tol=5e-4)
+        with torch.no_grad():
+            loss = d.p_losses(x0, t, eps)
+        check(f"{obj} loss", loss, oref.p_losses(x0, t, eps), tol=1e-5)
+        out[f"{obj}_loss"] = loss
+        # DDIM, 5 of 50 steps, eta 0.5 (src/hicdiff.py:622-664: the noise is derived from the CLIPPED x0 under these objectives).  (The linear
+        # schedule at T = 20 ends with beta = 1, alphas_cumprod = 0: predict_noise_from_start divides by it.)
+        d = R0.GaussianDiffusion(m, image_size=S, timesteps=50, sampling_timesteps=5, loss_type="l2", beta_schedule="linear", objective=obj,
+                                 ddim_sampling_eta=0.5)
+        torch.manual_seed(77)
+        x = d.sample(torch.zeros(B, 1, S, S))
+        oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=50, beta_schedule="linear", sampling_timesteps=5, ddim_sampling_eta=0.5,
+                               objective=obj)
+        check(f"{obj} ddim", x, oref.ddim_sample((B, 1, S, S), OD.TorchNoise(77)), tol=5e-4)
+        out[f"{obj}_ddim_x0"] = x
+    save("objectives", **out)
+
+
 def case_losses():
     out = {}
     B, S, T = 4, 40, 1000
@@ -661,6 +697,7 @@ CASES = {
     "tiny": case_tiny,
     "trajectories": case_trajectories,
     "losses": case_losses,
+    "objectives": case_objectives,
 }
 
 if __name__ == "__main__":

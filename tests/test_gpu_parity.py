@@ -163,6 +163,30 @@ def test_ddim_golden(eta):
     assert rel_err(g[f"ddim_eta{eta}_x0"], x) < CHAIN_TOL
 
 
+@pytest.mark.parametrize("objective", ["pred_x0", "pred_v"])
+def test_objectives_pred_x0_and_pred_v_golden(objective):
+    """GaussianDiffusion(objective=...) (src/hicdiff.py:441,566-580; no reference driver sets it): the same fused step with the two
+    coefficients that turn the network's output into x0 set for the objective -- 20-step ancestral chain, 5-of-50 DDIM (whose noise term is
+    derived from the clipped x0 under these objectives) and the loss value, against the reference's outputs."""
+    from hicdiff_amd.hicdiff import HostReplayNoise
+    g = golden("objectives")
+    D = diffusion_class("uncond")
+    d = D(_chain_model("uncond"), image_size=40, timesteps=20, loss_type="l2", beta_schedule="linear", objective=objective).cuda()
+    d.noise_source = HostReplayNoise(4242, "cuda")
+    stack = d.sample(torch.zeros(2, 1, 40, 40), return_all_timesteps=True)
+    for k in range(0, 20, 5):
+        assert rel_err(g[f"{objective}_x_after_t{k}"], stack[:, 20 - k]) < CHAIN_TOL, k
+    with torch.no_grad():                       # the loss VALUE (validation loops); the native training step is built for pred_noise, as the reference trains
+        val = d.p_losses(g["x0"].cuda(), g["t"].cuda(), g["eps"].cuda())
+    assert abs(val.item() - g[f"{objective}_loss"].item()) < 1e-4 * abs(g[f"{objective}_loss"].item())
+    with pytest.raises(NotImplementedError):
+        d.p_losses(g["x0"].cuda(), g["t"].cuda(), g["eps"].cuda())
+    d = D(_chain_model("uncond"), image_size=40, timesteps=50, sampling_timesteps=5, loss_type="l2", beta_schedule="linear", objective=objective,
+          ddim_sampling_eta=0.5).cuda()
+    d.noise_source = HostReplayNoise(77, "cuda")
+    assert rel_err(g[f"{objective}_ddim_x0"], d.sample(torch.zeros(2, 1, 40, 40))) < CHAIN_TOL
+
+
 @pytest.mark.parametrize("net", ["unet", "hicedrn3"])
 @pytest.mark.parametrize("sigma_0", [0.1, 1.0])
 def test_ddrm_chain_golden(net, sigma_0):

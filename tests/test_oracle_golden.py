@@ -263,3 +263,20 @@ def test_ddrm_general_chain_golden(deg):
     # V is orthogonal and V^T its transpose, as the sampler assumes
     V = g[pre + "V"]
     assert torch.allclose(V @ V.T, torch.eye(V.shape[0]), atol=2e-5) and torch.allclose(g[pre + "Vt"], V.T, atol=2e-5)
+
+
+def test_oracle_objectives_pred_x0_and_pred_v_reproduce_the_reference():
+    """objective = 'pred_x0' / 'pred_v' (src/hicdiff.py:566-580,733-741): 20-step ancestral chain, 5-of-50 DDIM (eta 0.5) and the loss value, against
+    fixtures the reference produced (tests/golden/make_golden.py::case_objectives)."""
+    from _util import oracle_unet
+    from oracle import diffusion as OD
+    g = golden("objectives")
+    model = oracle_unet("uncond")
+    for obj in ("pred_x0", "pred_v"):
+        ref = OD.DiffusionRef(model, image_size=40, timesteps=20, beta_schedule="linear", loss_type="l2", objective=obj)
+        final, kept = ref.p_sample_loop((2, 1, 40, 40), OD.TorchNoise(4242), keep_every=5)
+        for k in range(0, 20, 5):
+            assert rel_err(g[f"{obj}_x_after_t{k}"], kept[k]) < 1e-5, (obj, k)
+        assert abs(float(ref.p_losses(g["x0"], g["t"], g["eps"])) - float(g[f"{obj}_loss"])) <= 1e-5 * float(g[f"{obj}_loss"])
+        ddim = OD.DiffusionRef(model, image_size=40, timesteps=50, beta_schedule="linear", sampling_timesteps=5, ddim_sampling_eta=0.5, objective=obj)
+        assert rel_err(g[f"{obj}_ddim_x0"], ddim.ddim_sample((2, 1, 40, 40), OD.TorchNoise(77))) < 1e-5
