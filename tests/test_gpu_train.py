@@ -803,6 +803,60 @@ def test_gradient_stages_are_final_at_their_event(net):
     side.synchronize()
 
 
+def test_staged_reduction_starts_before_the_backward_pass_ends(monkeypatch):
+    """The point of the gradient stages: stage k's bucket is packed and its collective queued while the kernels of the later stages still run.
+    One process, the collective replaced by a recorder that drops a timing event on the side stream where the all-reduce would start:
+    every stage but the last must be ready to travel BEFORE the step's last kernel finishes, in stage order, and the bucket handed to
+    the collective must already hold the stage's final gradients (compared after the step with the flat buffer)."""
+    from hicdiff_amd._training import StagedReducer, trainer_for
+    d = _diffusion("cond", 8, 64)
+    d.train()
+    B, S = 4, 64
+    x0, lq = tiles(91, B, S).cuda(), tiles(92, B, S).cuda()
+    gen = torch.Generator().manual_seed(3)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()
+    d.p_losses([lq, x0], t, eps).backward()                 # creates the trainer, warms every kernel up
+    tr = trainer_for(d.model, B, S)
+    red = StagedReducer(tr.grads, tr.slots, tr.slot_stage)
+    marks, seen = [], []
+
+    class Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(bucket, group=None, async_op=False):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())              # the side stream, behind the stage's event wait and the pack
+        marks.append(ev)
+        seen.append(bucket.clone())                          # (also on the side stream: what the collective would send)
+        return Work()
+
+    monkeypatch.setattr(torch.distributed, "all_reduce", fake_all_reduce)
+    for p in d.model.parameters():
+        p.grad = None
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    loss = d.p_losses([lq, x0], t, eps)                     # queues the whole step on the current stream
+    red.launch(tr._wait_stage)                               # ... and the per-stage packs + collectives behind their events
+    end.record()                                             # behind the step's last kernel on the compute stream
+    red.finish()
+    torch.cuda.synchronize()
+    nst = len(red.runs)
+    assert len(marks) == nst == 5
+    total = start.elapsed_time(end)
+    at = [start.elapsed_time(m) for m in marks]
+    assert all(a < b for a, b in zip(at, at[1:])), at                      # stage order
+    assert all(a < total for a in at[:-1]), (at, total)                     # ready to travel while later stages are still being computed
+    assert at[0] < 0.85 * total, (at, total)                                # stage 0 (the output end) well before the end of the step
+    for k in range(nst):                                                    # what was handed over is final
+        pos = 0
+        for off, n in red.runs[k]:
+            assert torch.equal(seen[k][pos:pos + n], tr.grads[off:off + n]), k
+            pos += n
+    loss.backward()
+
+
 def test_adam_state_dict_round_trip_and_torch_layout():
     """The per-epoch checkpoint form of the pretrain scripts (pretrain/train_hicedrn_Diff.py:93-96: {'epoch', 'model_state_dict',
     'optimizer_state_dict'}): Adam.state_dict() has torch.optim.Adam's layout (it loads into one), and a run resumed from
