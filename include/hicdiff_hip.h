@@ -259,10 +259,11 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* arch, int 
 void hd_train_destroy(hd_trainer* t);
 const char* hd_train_last_error(const hd_trainer* t);
 
-/* Arithmetic of the 256-channel convolutions and of the weight-gradient GEMM: HD_PRECISION_BF16X3 (default: three bf16 MFMA products
- * per fp32 product, the arithmetic of the parity tests) or HD_TRAIN_PREC_BF16 (one bf16 product, fp32 accumulate: the "bf16 compute,
- * fp32 master weights" of mixed-precision training; gradients then carry bf16 rounding, ~1e-2 relative).  Master weights, gradients,
- * Adam state, FiLM / time MLP and every elementwise step stay fp32 in both. */
+/* Arithmetic of the wide 3x3 convolutions (the 8-wave kernel: hicedrn's 256-channel layers, the UNet's 32 x 32 level) and of the weight
+ * gradients of 3x3 layers with more than 64 input channels: HD_PRECISION_BF16X3 (default: three bf16 MFMA products per fp32 product, the
+ * arithmetic of the parity tests) or HD_TRAIN_PREC_BF16 (one bf16 product, fp32 accumulate: the "bf16 compute, fp32 master weights" of
+ * mixed-precision training; gradients then carry bf16 rounding, ~1e-2 relative; layers without a one-product kernel form keep the three
+ * products).  Master weights, gradients, Adam state, FiLM / time MLP and every elementwise step stay fp32 in both. */
 #define HD_TRAIN_PREC_BF16 2
 int hd_train_set_precision(hd_trainer* t, int mode);
 
