@@ -10,7 +10,9 @@ kernels of the later stages still run.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 
 import torch
 
@@ -75,7 +77,6 @@ class StagedReducer:
         """Queue pack + all-reduce of every stage.  wait_stage(k, stream_handle) makes the side stream wait for stage k's event."""
         if self.works:
             raise RuntimeError("StagedReducer.launch: the previous reduction was not finished")
-        import contextlib
         for k in range(len(self.runs)):
             if not self.runs[k]:
                 continue
@@ -89,7 +90,6 @@ class StagedReducer:
         """Sums back into the flat buffer; the current stream continues behind them."""
         if not self.works:
             return
-        import contextlib
         with (torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()):
             for k, w in self.works:
                 w.wait()                                         # GPU: the side stream waits for the collective's stream; CPU: blocks
@@ -200,7 +200,6 @@ class NativeTrainer:
         if rc != 0:
             raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode() + " / " + (self.lib.hd_last_error(None) or b"").decode())
         self.serial = getattr(self, "serial", 0) + 1
-        import os
         if _dist_world() > 1 and os.environ.get("HICDIFF_DP_OVERLAP", "1") != "0":
             # every kernel of the step is queued; queue the per-stage sums behind their events now, so that stage k travels over xGMI
             # while stages k+1.. are still being computed.  (HICDIFF_DP_OVERLAP=0: one all-reduce of the whole buffer in Adam.step.)
@@ -258,7 +257,6 @@ class _NativeLoss(torch.autograd.Function):
 def trainer_for(model, B: int, S: int) -> NativeTrainer:
     """The network's trainer, re-created when the batch shape, the device or the requested arithmetic changed.  The arithmetic is
     `model.train_precision` ('bf16x3' | 'bf16') if set, else the environment's HICDIFF_TRAIN_PRECISION, else 'bf16x3'."""
-    import os
     precision = getattr(model, "train_precision", None) or os.environ.get("HICDIFF_TRAIN_PRECISION", "bf16x3")
     tr = model.__dict__.get("_hd_trainer")
     if tr is None or (tr.B, tr.S) != (B, S) or tr.device != next(model.parameters()).device or not tr.still_seated() or tr.precision != precision:

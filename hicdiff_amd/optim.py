@@ -71,6 +71,9 @@ class Adam:
                     m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                     k = int(float(st["step"]))
+                    del self._loaded["state"][index[id(p)]]           # consumed: the flat buffers carry it from here on
+                if not self._loaded["state"]:
+                    self._loaded = None
         return m, v, k
 
     def zero_grad(self, set_to_none=True):
