@@ -811,7 +811,7 @@ def test_staged_reduction_starts_before_the_backward_pass_ends(monkeypatch):
     from hicdiff_amd._training import StagedReducer, trainer_for
     d = _diffusion("cond", 8, 64)
     d.train()
-    B, S = 4, 64
+    B, S = 16, 64                 # 14 ms of kernels against ~1-6 ms of host enqueue: at 4 tiles the step is host-bound and nothing can overlap
     x0, lq = tiles(91, B, S).cuda(), tiles(92, B, S).cuda()
     gen = torch.Generator().manual_seed(3)
     t, eps = torch.randint(0, 1000, (B,), generator=gen).cuda(), torch.randn(x0.shape, generator=gen).cuda()
@@ -848,7 +848,7 @@ def test_staged_reduction_starts_before_the_backward_pass_ends(monkeypatch):
     at = [start.elapsed_time(m) for m in marks]
     assert all(a < b for a, b in zip(at, at[1:])), at                      # stage order
     assert all(a < total for a in at[:-1]), (at, total)                     # ready to travel while later stages are still being computed
-    assert at[0] < 0.85 * total, (at, total)                                # stage 0 (the output end) well before the end of the step
+    assert at[0] < 0.8 * total, (at, total)                                 # stage 0 (the output end) well before the end of the step (measured: 0.57)
     for k in range(nst):                                                    # what was handed over is final
         pos = 0
         for off, n in red.runs[k]:
