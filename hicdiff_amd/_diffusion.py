@@ -377,8 +377,6 @@ class DiffusionCore(nn.Module):
     def _native_loss(self, x_start, cond, t, noise, level=None):
         """loss tensor with `.backward()` (train.py:131-132): forward, loss and every gradient in one engine call."""
         from ._training import trainer_for
-        if self.objective != "pred_noise":
-            raise NotImplementedError("the reference trains with objective='pred_noise' only")
         if self.loss_type not in ("l1", "l2"):
             raise ValueError(f"invalid loss type {self.loss_type}")
         if level is not None:                                            # SR3: x_t = level x0 + sqrt(1 - level^2) eps, plain mean
@@ -392,7 +390,7 @@ class DiffusionCore(nn.Module):
         tr = trainer_for(self.model, x_start.shape[0], x_start.shape[-1])
         a_t = self.sqrt_alphas_cumprod.gather(-1, t)
         s_t = self.sqrt_one_minus_alphas_cumprod.gather(-1, t)
-        return tr.loss_backward(x_start, cond, t, noise, a_t, s_t, self.loss_type == "l2")
+        return tr.loss_backward(x_start, cond, t, noise, a_t, s_t, self.loss_type == "l2", self.objective)      # target: _target's (src/hicdiff.py:733-741)
 
     def _target(self, x_start, t, noise):
         if self.objective == "pred_noise":

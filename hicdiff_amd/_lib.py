@@ -92,6 +92,7 @@ SYMBOLS = {
     "hd_train_destroy": (None, [_P]),
     "hd_train_last_error": (C.c_char_p, [_P]),
     "hd_train_set_precision": (C.c_int, [_P, C.c_int]),
+    "hd_train_set_objective": (C.c_int, [_P, C.c_int]),
     "hd_train_param_count": (C.c_int, [_P, _P]),
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "hd_train_stage_count": (C.c_int, [_P]),

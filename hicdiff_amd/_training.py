@@ -176,8 +176,13 @@ class NativeTrainer:
             n *= s
         return self.grads[off:off + n].view(shape)
 
-    def loss_backward(self, x_start, cond, t, noise, a_t, s_t, l2: bool):
+    def loss_backward(self, x_start, cond, t, noise, a_t, s_t, l2: bool, objective: str = "pred_noise"):
         B, _, S, _ = x_start.shape
+        if objective != getattr(self, "objective", "pred_noise"):
+            rc = self.lib.hd_train_set_objective(self.h, {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}[objective])
+            if rc != 0:
+                raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
+            self.objective = objective
         if (B, S) != (self.B, self.S):
             raise ValueError(f"trainer sized for batches of {self.B} tiles of {self.S}x{self.S}, got {B} of {S}x{S}")
         f = lambda v: None if v is None else v.detach().to(torch.float32).contiguous()

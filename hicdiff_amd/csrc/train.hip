@@ -1052,14 +1052,20 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 // ---- loss ---------------------------------------------------------------------------------------------------------
 // per[b] = mean_i f(out - eps); dout = f'(out - eps) / (B * n)   (l2: f = d^2; l1: f = |d|; p2 weight == 1)
 // per[b] = per-sample loss, per[B + b] = sum of the sample's dout (the last convolution's bias gradient)
+// objective (src/hicdiff.py:733-741): 0 the target is the noise; 1 x_start itself; 2 v = a_t eps - s_t x_start (predict_v, :542-546)
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ eps, int n, int B, int l2,
-                                                        float* __restrict__ per, float* __restrict__ dout) {
+                                                        float* __restrict__ per, float* __restrict__ dout, int objective = 0,
+                                                        const float* __restrict__ x0 = nullptr, const float* __restrict__ a_t = nullptr,
+                                                        const float* __restrict__ s_t = nullptr) {
     __shared__ float red[256], red2[256];
     const int b = blockIdx.x;
     const float inv = 1.f / ((float)B * (float)n);
+    const float av = objective == 2 ? a_t[b] : 0.f, sv = objective == 2 ? s_t[b] : 0.f;
     float s = 0.f, sg = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const float d = out[(size_t)b * n + i] - eps[(size_t)b * n + i];
+        const size_t e = (size_t)b * n + i;
+        const float target = objective == 0 ? eps[e] : objective == 1 ? x0[e] : av * eps[e] - sv * x0[e];
+        const float d = out[e] - target;
         s += l2 ? d * d : fabsf(d);
         const float g = l2 ? 2.f * d * inv : (d > 0.f ? inv : d < 0.f ? -inv : 0.f);
         dout[(size_t)b * n + i] = g;
@@ -1311,6 +1317,7 @@ struct hd_trainer {
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
     int slot_stage_of_block(int i) const { return (nres - 1 - i) * std::min(4, nres) / nres; }
+    int objective = 0;                    // hd_train_set_objective: what the network's output is compared with (0 noise, 1 x_start, 2 v)
     float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
     const float* cur_grads = nullptr;     // the gradient buffer of the step being queued
     size_t o_head_w = 0, o_head_b = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_bt_w = 0, o_bt_b = 0, o_tail_w = 0, o_tail_b = 0;
@@ -1511,6 +1518,13 @@ int hd_train_param_count(const hd_trainer* t, long long* total_floats) {
     return (int)t->slots.size();
 }
 
+int hd_train_set_objective(hd_trainer* t, int objective) {
+    if (!t || objective < 0 || objective > 2) return HD_EINVAL;
+    if (objective != 0 && t->arch.sr3) return tfail(t, HD_EINVAL, "the SR3 flavour trains on the noise only (src/hicdiff_sr3.py has no objective)");
+    t->objective = objective;
+    return HD_OK;
+}
+
 int hd_train_stage_count(const hd_trainer* t) { return t ? (int)t->stage_ev.size() : HD_EINVAL; }
 
 int hd_train_slot_stage(const hd_trainer* t, int slot, int* stage) {
@@ -1645,7 +1659,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         o.precision = HD_PREC_BF16X3;
         TR_TRY(launch_conv(o, st, nullptr));
     }
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, st, tr->out, noise, HW, B, l2 ? 1 : 0, tr->per, tr->dout);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, st, tr->out, noise, HW, B, l2 ? 1 : 0, tr->per, tr->dout, tr->objective, x_start, a_t, s_t);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, st, tr->per, B, loss, grads + tr->o_tail_b);
     TR_TRY(check_launch("loss"));
 

@@ -267,6 +267,10 @@ const char* hd_train_last_error(const hd_trainer* t);
 #define HD_TRAIN_PREC_BF16 2
 int hd_train_set_precision(hd_trainer* t, int mode);
 
+/* What the network's output is compared with (GaussianDiffusion(objective = ...), src/hicdiff.py:441,733-741): 0 the noise (default; the
+ * only one a reference driver uses), 1 x_start, 2 v = a_t noise - s_t x_start (predict_v, :542-546).  Not for SR3 nets. */
+int hd_train_set_objective(hd_trainer* t, int objective);
+
 /* Number of parameter tensors; *total_floats = length of the flat arrays. */
 int hd_train_param_count(const hd_trainer* t, long long* total_floats);
 /* Slot i: state_dict key, offset in floats, shape (padded with 1s to 4 entries), rank. */

@@ -13,7 +13,7 @@ import torch
 from . import nets as ON
 
 
-def loss_and_grads(sd, cfg, buf, x0, t, eps, cond=None, loss_type="l2"):
+def loss_and_grads(sd, cfg, buf, x0, t, eps, cond=None, loss_type="l2", objective="pred_noise"):
     """t: int64 timesteps; for SR3 nets (cfg.sr3) the continuous noise level as a float tensor (src/hicdiff_sr3.py:750-792:
     x_t = level x0 + sqrt(1 - level^2) eps, plain mean reduction)."""
     p = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
@@ -26,7 +26,8 @@ def loss_and_grads(sd, cfg, buf, x0, t, eps, cond=None, loss_type="l2"):
         a = buf["sqrt_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
         s = buf["sqrt_one_minus_alphas_cumprod"].gather(-1, t).reshape(-1, 1, 1, 1)
         out = fn(p, a * x0 + s * eps, t, cond, cfg)
-        per = (out - eps).abs() if loss_type == "l1" else (out - eps) ** 2
+        target = eps if objective == "pred_noise" else x0 if objective == "pred_x0" else a * eps - s * x0      # src/hicdiff.py:733-741, predict_v :542-546
+        per = (out - target).abs() if loss_type == "l1" else (out - target) ** 2
         loss = (per.reshape(per.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"].gather(-1, t)).mean()
     loss.backward()
     return loss.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in p.items()}

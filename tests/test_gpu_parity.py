@@ -176,11 +176,11 @@ def test_objectives_pred_x0_and_pred_v_golden(objective):
     stack = d.sample(torch.zeros(2, 1, 40, 40), return_all_timesteps=True)
     for k in range(0, 20, 5):
         assert rel_err(g[f"{objective}_x_after_t{k}"], stack[:, 20 - k]) < CHAIN_TOL, k
-    with torch.no_grad():                       # the loss VALUE (validation loops); the native training step is built for pred_noise, as the reference trains
+    with torch.no_grad():                       # the loss VALUE through the inference engine (validation loops)
         val = d.p_losses(g["x0"].cuda(), g["t"].cuda(), g["eps"].cuda())
     assert abs(val.item() - g[f"{objective}_loss"].item()) < 1e-4 * abs(g[f"{objective}_loss"].item())
-    with pytest.raises(NotImplementedError):
-        d.p_losses(g["x0"].cuda(), g["t"].cuda(), g["eps"].cuda())
+    val = d.p_losses(g["x0"].cuda(), g["t"].cuda(), g["eps"].cuda())          # ... and from the native training step (train mode, autograd on)
+    assert val.requires_grad and abs(val.item() - g[f"{objective}_loss"].item()) < 1e-4 * abs(g[f"{objective}_loss"].item())
     d = D(_chain_model("uncond"), image_size=40, timesteps=50, sampling_timesteps=5, loss_type="l2", beta_schedule="linear", objective=objective,
           ddim_sampling_eta=0.5).cuda()
     d.noise_source = HostReplayNoise(77, "cuda")
