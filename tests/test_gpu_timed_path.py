@@ -399,3 +399,24 @@ def test_bench_strong_scaling_form_two_ranks():
     assert abs(line["value"] - 6 / (1000 * line["ms_per_step"] * 1e-3)) < 1e-3 * line["value"]
     bad = subprocess.run(base + ["--total-tiles", "7"], env=env, capture_output=True, timeout=120)
     assert bad.returncode != 0 and b"total % gpus" in bad.stderr
+
+
+def test_bench_training_two_ranks_on_one_gpu():
+    """`bench.py --workload hicedrn64_train --gpus 2` (BASELINE configs[4]'s data-parallel form) rehearsed on one card over gloo: both ranks
+    step together -- the gradients are summed stage by stage behind the backward pass -- and the line reports the whole job's tiles/s."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HICDIFF_BENCH_BACKEND="gloo", HICDIFF_DEVICE="0")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "hicedrn64_train", "--blocks", "2", "--tile", "16",
+                          "--batch", "4", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["unit"] == "tiles/s"
+    assert abs(line["value"] - 2 * 4 / (line["ms_per_step"] * 1e-3)) < 1e-2 * line["value"]
+    assert "stage by stage" in line["config"]["parallelism"]
+    assert line["loss_first_last"][1] < line["loss_first_last"][0]
