@@ -105,6 +105,8 @@ SYMBOLS = {
                                           C.c_uint32, _P]),
     "hd_gather_cols": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "hd_kvec_matmul": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "hd_sandwich_matmul": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "hd_dense_matmul": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "hd_fwht": (C.c_int, [_P, C.c_int, C.c_int, C.c_float, _P]),
     "hd_split_pieces": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "hd_stitch_pieces": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),

@@ -108,6 +108,64 @@ __global__ __launch_bounds__(256) void kvec_matmul_kernel(const float* __restric
     dst[i] = acc;
 }
 
+// dst[i] = A x[i] Bm for n images of S x S (S <= 64, all row-major): the separable operators' V / V^T / U / U^T (Deblurring, Deblurring2D,
+// src/functions/svd_replacement.py:401-541: a Kronecker factor on the rows and one on the columns of every channel image).  One workgroup
+// per image; A, Bm, the image and the intermediate T = x Bm live in LDS (64 KB at S = 64); fp32 FMA in a fixed order.
+__global__ __launch_bounds__(256) void sandwich_matmul_kernel(const float* __restrict__ A, const float* __restrict__ x, const float* __restrict__ Bm,
+                                                              float* __restrict__ dst, int S) {
+    extern __shared__ float sm[];
+    float *As = sm, *Bs = sm + S * S, *Xs = sm + 2 * S * S, *Ts = sm + 3 * S * S;
+    const float* xi = x + (size_t)blockIdx.x * S * S;
+    for (int i = threadIdx.x; i < S * S; i += 256) { As[i] = A[i]; Bs[i] = Bm[i]; Xs[i] = xi[i]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * S; i += 256) {
+        const int r = i / S, c = i - r * S;
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) acc += Xs[r * S + k] * Bs[k * S + c];
+        Ts[i] = acc;
+    }
+    __syncthreads();
+    float* o = dst + (size_t)blockIdx.x * S * S;
+    for (int i = threadIdx.x; i < S * S; i += 256) {
+        const int r = i / S, c = i - r * S;
+        float acc = 0.f;
+        for (int k = 0; k < S; ++k) acc += As[r * S + k] * Ts[k * S + c];
+        o[i] = acc;
+    }
+}
+
+// dst[n][m] = sum_k src[n][k] mat[k][m] for any sizes: the dense-SVD operator (GeneralH, src/functions/svd_replacement.py:72-107 -- d x d factors,
+// memory-hungry upstream too, used by no driver).  64 x 64 output tiles, 16-deep K steps through LDS, 4 x 4 outputs per thread.
+__global__ __launch_bounds__(256) void dense_matmul_kernel(const float* __restrict__ src, const float* __restrict__ mat, float* __restrict__ dst,
+                                                           int N, int K, int M) {
+    __shared__ float sa[16][64 + 1], sb[16][64 + 1];
+    const int n0 = blockIdx.y * 64, m0 = blockIdx.x * 64, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+            const int kk = i & 15, r = i >> 4;                      // src tile: 64 rows x 16 k
+            sa[kk][r] = (n0 + r < N && k0 + kk < K) ? src[(size_t)(n0 + r) * K + k0 + kk] : 0.f;
+            const int c = i & 63, k2 = i >> 6;                      // mat tile: 16 k x 64 columns
+            sb[k2][c] = (k0 + k2 < K && m0 + c < M) ? mat[(size_t)(k0 + k2) * M + m0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = sa[kk][ty * 4 + u]; b[u] = sb[kk][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+        }
+        __syncthreads();
+    }
+    for (int u = 0; u < 4; ++u)
+        for (int v = 0; v < 4; ++v)
+            if (n0 + ty * 4 + u < N && m0 + tx * 4 + v < M) dst[(size_t)(n0 + ty * 4 + u) * M + m0 + tx * 4 + v] = acc[u][v];
+}
+
 // In-place fast Walsh-Hadamard transform of N rows of length L = 2^p (<= 4096), scaled by `scale` (the reference divides by img_dim:
 // src/functions/svd_replacement.py:287-297); one workgroup per row, the row lives in LDS.
 __global__ __launch_bounds__(256) void fwht_kernel(float* __restrict__ data, int L, float scale) {
@@ -164,6 +222,22 @@ int hd_kvec_matmul(const float* src, const float* mat, float* dst, size_t N, int
     if (N == 0) return HD_OK;
     hipLaunchKernelGGL(kvec_matmul_kernel, dim3((unsigned)((N * K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, mat, dst, N, K);
     return check("kvec_matmul");
+}
+
+int hd_sandwich_matmul(const float* A, const float* x, const float* Bm, float* dst, int n, int S, void* stream) {
+    if (!A || !x || !Bm || !dst || n < 0 || S < 1 || S > 64 || x == dst) return HD_EINVAL;
+    if (n == 0) return HD_OK;
+    static bool raised = false;
+    if (!raised) { (void)hipFuncSetAttribute((const void*)sandwich_matmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); raised = true; }
+    hipLaunchKernelGGL(sandwich_matmul_kernel, dim3(n), dim3(256), (size_t)4 * S * S * sizeof(float), (hipStream_t)stream, A, x, Bm, dst, S);
+    return check("sandwich_matmul");
+}
+
+int hd_dense_matmul(const float* src, const float* mat, float* dst, int N, int K, int M, void* stream) {
+    if (!src || !mat || !dst || N < 0 || K < 1 || M < 1 || src == dst) return HD_EINVAL;
+    if (N == 0) return HD_OK;
+    hipLaunchKernelGGL(dense_matmul_kernel, dim3((M + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, mat, dst, N, K, M);
+    return check("dense_matmul");
 }
 
 int hd_fwht(float* data, int N, int L, float scale, void* stream) {

@@ -1,10 +1,11 @@
 """SVD-free degradation operators of the DDRM sampler: drop-in for ``src/functions/svd_replacement.py``.
 
 HiCDiff hard-codes ``deg='deno'`` (inference.py:44, train.py:45), i.e. ``Denoising`` (identity H, all singular values 1),
-which ``hd_ddrm_step`` fuses.  The rest of the reference's operator zoo (:72-541) is here too, built from three HIP
+which ``hd_ddrm_step`` fuses.  The rest of the reference's operator zoo (:72-541) is here too, built from five HIP
 primitives -- a column gather (every permutation / selection / zero padding), one small matrix applied to many short
-vectors (per-patch and per-pixel factors) and the fast Walsh-Hadamard transform -- plus plain library GEMMs for the dense
-S x S factors of the blur operators.  Index tables and the tiny SVDs are built once, on the host, at construction.
+vectors (per-patch and per-pixel factors), the fast Walsh-Hadamard transform, S x S factors on both sides of every image
+(the separable blur operators) and a plain dense product (GeneralH) -- no library GEMM.  Index tables and the tiny SVDs
+are built once, on the host, at construction.
 
 Conventions are the reference's: vectors go in as (B, ...) and come out as (B, D); the spectral ordering of every
 operator (which entry of ``V^T x`` belongs to which singular value) is the reference's, because replayed noise and the
@@ -53,6 +54,29 @@ def kvec_matmul(src, mat):
     rc = L.load().hd_kvec_matmul(C.c_void_p(s.data_ptr()), C.c_void_p(mat.data_ptr()), C.c_void_p(dst.data_ptr()), s.numel() // K, K, _stream(s.device))
     if rc != 0:
         raise L.HdError(rc, "hd_kvec_matmul failed (K <= 64)")
+    return dst
+
+
+def sandwich_matmul(A, x, Bm):
+    """A @ x[i] @ Bm for a stack x of S x S images (S <= 64): hd_sandwich_matmul."""
+    S = A.shape[0]
+    xs = x.contiguous().float()
+    dst = torch.empty_like(xs)
+    rc = L.load().hd_sandwich_matmul(C.c_void_p(A.contiguous().data_ptr()), C.c_void_p(xs.data_ptr()), C.c_void_p(Bm.contiguous().data_ptr()),
+                                     C.c_void_p(dst.data_ptr()), xs.numel() // (S * S), S, _stream(xs.device))
+    if rc != 0:
+        raise L.HdError(rc, "hd_sandwich_matmul failed (S <= 64)")
+    return dst
+
+
+def dense_matmul(src, mat):
+    """src [N, K] @ mat [K, M]: hd_dense_matmul."""
+    s, m = src.contiguous().float(), mat.contiguous().float()
+    dst = torch.empty((s.shape[0], m.shape[1]), device=s.device, dtype=torch.float32)
+    rc = L.load().hd_dense_matmul(C.c_void_p(s.data_ptr()), C.c_void_p(m.data_ptr()), C.c_void_p(dst.data_ptr()), s.shape[0], s.shape[1], m.shape[1],
+                                  _stream(s.device))
+    if rc != 0:
+        raise L.HdError(rc, "hd_dense_matmul failed")
     return dst
 
 
@@ -115,7 +139,7 @@ def _pad_zeros(vec, d_total):
 
 
 class GeneralH(H_functions):
-    """Any dense H through its full SVD (:72-107; memory-hungry upstream too): plain library GEMMs."""
+    """Any dense H through its full SVD (:72-107; memory-hungry upstream too): four dense factors applied by hd_dense_matmul."""
 
     def __init__(self, H):
         U, s, V = torch.svd(H.detach().float().cpu(), some=False)            # host LAPACK, as the reference on its CPU path
@@ -123,11 +147,12 @@ class GeneralH(H_functions):
         s[s < 1e-3] = 0
         dev = H.device
         self._U, self._V, self._singulars = U.to(dev), V.to(dev), s.to(dev)
+        self._Ut, self._Vt = self._U.T.contiguous(), self._V.T.contiguous()
 
-    def V(self, vec): return _flat(vec) @ self._V.T
-    def Vt(self, vec): return _flat(vec) @ self._V
-    def U(self, vec): return _flat(vec) @ self._U.T
-    def Ut(self, vec): return _flat(vec) @ self._U
+    def V(self, vec): return dense_matmul(_flat(vec), self._Vt)
+    def Vt(self, vec): return dense_matmul(_flat(vec), self._V)
+    def U(self, vec): return dense_matmul(_flat(vec), self._Ut)
+    def Ut(self, vec): return dense_matmul(_flat(vec), self._U)
     def singulars(self): return self._singulars
     def add_zeros(self, vec): return _pad_zeros(vec, self._V.shape[0])
 
@@ -285,11 +310,11 @@ def _conv_matrix(kernel, rows, img_dim, stride=1, reflect=False):
 
 class _Separable(H_functions):
     """Shared body of the operators whose H is a Kronecker product of two small matrices acting on the rows and columns of
-    every channel image: V x = V1 X V2^T etc. are dense S x S library GEMMs; the singular-value ordering is a column gather."""
+    every channel image: V x = V1 X V2^T etc. are S x S products on both sides of every image (hd_sandwich_matmul); the singular-value ordering is a column gather."""
 
     def _lr(self, A, vec, Bm, dim):
         x = _flat(vec).reshape(vec.shape[0] * self.channels, dim, dim)
-        return (A @ x @ Bm).reshape(vec.shape[0], self.channels, -1)
+        return sandwich_matmul(A, x, Bm).reshape(vec.shape[0], self.channels, -1)
 
 
 class Deblurring(_Separable):

@@ -157,6 +157,10 @@ int hd_ddrm_general_update(const float* vt_x0, const float* vt_et, const float* 
  * Walsh-Hadamard transform of N rows of length L = 2^p <= 4096 times `scale`. */
 int hd_gather_cols(const float* src, const int* idx, float* dst, int B, int Dsrc, int Ddst, void* stream);
 int hd_kvec_matmul(const float* src, const float* mat, float* dst, size_t N, int K, void* stream);
+/* dst[i] = A x[i] Bm for n row-major S x S images, S <= 64 (the separable blur operators' V / V^T / U / U^T,
+ * src/functions/svd_replacement.py:401-541); dst[n][m] = sum_k src[n][k] mat[k][m] for any sizes (GeneralH's dense factors, :72-107). */
+int hd_sandwich_matmul(const float* A, const float* x, const float* Bm, float* dst, int n, int S, void* stream);
+int hd_dense_matmul(const float* src, const float* mat, float* dst, int N, int K, int M, void* stream);
 int hd_fwht(float* data, int N, int L, float scale, void* stream);
 
 /* hd_ddpm_step / hd_ddrm_step with device-generated noise replay a captured hipGraph of the whole step

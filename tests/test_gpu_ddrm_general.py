@@ -63,6 +63,26 @@ def test_operator_matches_reference_matrices(deg, C_):
         assert tuple(y.reshape(2, -1).shape) == (2, M) and keep.shape[0] == M
 
 
+def test_general_h_dense_factors_and_matmul_primitives():
+    """GeneralH (src/functions/svd_replacement.py:72-107): any dense H through its SVD, the four factors applied by hd_dense_matmul; and the
+    two GEMM primitives against fp64 products on the host (sizes that are not multiples of the 64-wide tiles included)."""
+    from hicdiff_amd.functions import svd_replacement as SV
+    gen = torch.Generator().manual_seed(12)
+    Hm = torch.randn(50, 100, generator=gen)                          # 50 measurements of a 100-dimensional signal
+    H = SV.GeneralH(Hm.cuda())
+    x = torch.randn(3, 100, generator=gen).cuda()
+    y = H.H(x)                                                         # U S V^T x
+    assert rel_err(x.cpu().double() @ Hm.double().T, y.cpu().double()) < 1e-5
+    assert rel_err(x, H.V(H.Vt(x))) < 1e-5 and rel_err(y, H.U(H.Ut(y))) < 1e-5         # orthogonal factors
+    assert tuple(H.add_zeros(y).shape) == (3, 100) and H.singulars().shape[0] == 50
+    a, b = torch.randn(130, 75, generator=gen), torch.randn(75, 201, generator=gen)
+    assert rel_err(a.double() @ b.double(), SV.dense_matmul(a.cuda(), b.cuda()).cpu().double()) < 1e-6
+    A, Bm, X = torch.randn(40, 40, generator=gen), torch.randn(40, 40, generator=gen), torch.randn(5, 40, 40, generator=gen)
+    assert rel_err(A.double() @ X.double() @ Bm.double(), SV.sandwich_matmul(A.cuda(), X.cuda(), Bm.cuda()).cpu().double()) < 1e-6
+    with pytest.raises(Exception):
+        SV.sandwich_matmul(torch.randn(65, 65).cuda(), torch.randn(1, 65, 65).cuda(), torch.randn(65, 65).cuda())     # S <= 64
+
+
 def test_makefunc_builds_every_degradation_and_refuses_unknown_names():
     from hicdiff_amd.functions import svd_replacement as SV
     from hicdiff_amd.functions.H_func import MakeFunc
