@@ -256,7 +256,7 @@ int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, 
  * hicedrn_sr3_Diff.py) and the UNet (src/hicdiff.py, hicdiff_condition.py, hicdiff_sr3.py; width a multiple of 64, at most four levels). */
 typedef struct hd_trainer hd_trainer;
 
-/* Sizes the saved activations for batches of exactly B tiles of 1xSxS (hicedrn: two tensors of B*S*S*256 floats per residual block,
+/* Sizes the saved activations for batches of exactly B tiles of 1xSxS (hicedrn: three tensors of B*S*S*256 floats per residual block -- 25.8 GB at 64 tiles of 64x64 and 32 blocks,
  * S a multiple of 8, 8..64; UNet: one arena sized by walking a step without launching, S divisible by 2^(levels-1) with a last map of at
  * least 4x4).  HD_EINVAL for shapes outside that, HD_ENOMEM when the device cannot hold them. */
 int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* arch, int B, int S);
