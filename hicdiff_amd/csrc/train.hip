@@ -1317,6 +1317,7 @@ struct hd_trainer {
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
     int slot_stage_of_block(int i) const { return (nres - 1 - i) * std::min(4, nres) / nres; }
+    void* fjobs_dev = nullptr; int fjobs_n = 0, ftiles = 0;    // hicedrn: the job table of prep_filters_kernel (every block's two packed images in one launch)
     int objective = 0;                    // hd_train_set_objective: what the network's output is compared with (0 noise, 1 x_start, 2 v)
     float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
     const float* cur_grads = nullptr;     // the gradient buffer of the step being queued
@@ -1474,6 +1475,24 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
             w->w = (float*)need(dev_alloc<float>(t, wn));
             w->wsplit = (unsigned short*)need(dev_alloc<unsigned short>(t, wn * 2));
         }
+    if (ok) {
+        // one table for prep_filters_kernel (train_unet.inc): forward image and flipped-transposed data-gradient image of all n + 1 shared
+        // 256 -> 256 convolutions in ONE launch per step (round 2: pack, split, flip, pack, split and two memsets per layer: 165 launches + 66
+        // memsets, 1.9 ms of a 157 ms step)
+        std::vector<FilterJob> jobs(n + 1);
+        int tiles = 0;
+        for (int i = 0; i <= n; ++i) {
+            FilterJob& j = jobs[i];
+            j = FilterJob{};
+            j.src = (long long)t->o_conv_w[i]; j.cout = F; j.cin_src = F; j.kk = 9; j.standardize = 0; j.unshuffle = 0;
+            j.cinF = F; j.tapsF = 9; j.ckF = 32; j.coutpadF = F; j.ckB = 32; j.coutpadB = F;
+            j.fw = t->fwd[i].w; j.fws = t->fwd[i].wsplit; j.bw = t->bwd[i].w; j.bws = t->bwd[i].wsplit;
+            j.first = i * F; j.tile0 = tiles; tiles += (F / 32) * (F / 32);
+        }
+        t->fjobs_dev = need(dev_alloc<FilterJob>(t, jobs.size()));
+        if (t->fjobs_dev && hipMemcpy(t->fjobs_dev, jobs.data(), jobs.size() * sizeof(FilterJob), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        t->fjobs_n = n + 1; t->ftiles = tiles;
+    }
     t->tail_fwd.KH = t->tail_fwd.KW = 3; t->tail_fwd.Cin = F; t->tail_fwd.Cout = 1; t->tail_fwd.CoutPad = 64; t->tail_fwd.ck = 32;
     t->tail_fwd.w = (float*)need(dev_alloc<float>(t, (size_t)9 * F * 64));
     t->tail_fwd.wsplit = (unsigned short*)need(dev_alloc<unsigned short>(t, (size_t)9 * F * 64 * 2));
@@ -1602,17 +1621,23 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     if (sr3 != (t_float != 0)) return tfail(tr, HD_EINVAL, "SR3 nets take the continuous noise level (float32); the others integer timesteps");
     const size_t act = (size_t)B * HW * F;
     tr->err.clear();
-    // ---- weights: forward image, flipped-transposed image for the data gradient
+    // ---- weights: forward image and flipped-transposed image for the data gradient of every shared convolution, one launch
+    static const bool per_layer_prep = getenv("HICDIFF_TRAIN_PREP_PER_LAYER") != nullptr;       // A/B: round 2's five launches per layer
+    if (!per_layer_prep) {
+        hipLaunchKernelGGL(prep_filters_kernel, dim3(tr->ftiles), dim3(256), 0, st, params, (const FilterJob*)tr->fjobs_dev, tr->fjobs_n, (const double2*)nullptr);
+        TR_TRY(check_launch("prep_filters"));
+    }
     for (int i = 0; i <= n; ++i) {
+        tr->fwd[i].bias = const_cast<float*>(params + tr->o_conv_b[i]);
+        tr->bwd[i].bias = nullptr;
+        if (!per_layer_prep) continue;
         const float* w = params + tr->o_conv_w[i];
         TR_TRY(launch_pack_conv(w, tr->fwd[i].w, F, F, 3, 3, F, 0, 0, st));
         TR_TRY(launch_split_conv(tr->fwd[i].w, tr->fwd[i].wsplit, 9, F, F, 16, st));
-        tr->fwd[i].bias = const_cast<float*>(params + tr->o_conv_b[i]);
         hipLaunchKernelGGL(flip_weight_kernel, dim3((unsigned)(((size_t)9 * F * F + 255) / 256)), dim3(256), 0, st, w, F, F, tr->wt_tmp);
         TR_TRY(check_launch("flip_weight"));
         TR_TRY(launch_pack_conv(tr->wt_tmp, tr->bwd[i].w, F, F, 3, 3, F, 0, 0, st));
         TR_TRY(launch_split_conv(tr->bwd[i].w, tr->bwd[i].wsplit, 9, F, F, 16, st));
-        tr->bwd[i].bias = nullptr;
     }
     TR_TRY(launch_pack_conv(params + tr->o_tail_w, tr->tail_fwd.w, 1, F, 3, 3, 64, 0, 0, st));
     TR_TRY(launch_split_conv(tr->tail_fwd.w, tr->tail_fwd.wsplit, 9, F, 64, 16, st));
