@@ -932,6 +932,45 @@ __global__ __launch_bounds__(256) void lin_fwd_kernel(const float* __restrict__ 
     }
 }
 
+// The activated input of the per-block FiLM projections, once per step instead of once per output column: A[b][k] = act(X[b][k]) and its
+// transpose AT[k][b] (Bp = the batch padded to whole waves; padding columns are zero).
+__global__ __launch_bounds__(256) void act_rows_kernel(const float* __restrict__ X, int Bn, int K, int act, int Bp, float* __restrict__ A, float* __restrict__ AT) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)Bp * K) return;
+    const int b = (int)(i / K), k = (int)(i % K);
+    const float v = b < Bn ? act_f(X[(size_t)b * K + k], act) : 0.f;
+    if (b < Bn) A[i] = v;
+    AT[(size_t)k * Bp + b] = v;
+}
+
+// Y[b][n] = bias[n] + sum_k AT[k][b] W[n][k] with one LANE per sample: the wave walks k once for four output columns, its loads of AT are one
+// coalesced row per k and the four weights of a k are wave-uniform.  (lin_fwd_kernel spends a wave per column and sample, with a shuffle
+// reduction and an activation per term: 1.5 ms for hicedrn's 32 x 512 FiLM columns at 64 samples, 89 % of it exp.)  grid = (N / 4 / 4, layers, Bp / 64).
+__global__ __launch_bounds__(256) void lin_fwd_t_kernel(const float* __restrict__ AT, int Bp, const float* __restrict__ W, const float* __restrict__ bias, int Bn, int K,
+                                                        int N, float* __restrict__ Y, int ldy, size_t wstride, size_t bstride, size_t ystride) {
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + wv) * 4, b = blockIdx.z * 64 + lane;
+    if (n0 >= N) return;
+    W += blockIdx.y * wstride + (size_t)n0 * K; bias += blockIdx.y * bstride; Y += blockIdx.y * ystride;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* at = AT + b;
+    for (int k = 0; k < K; k += 4) {
+        float x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = at[(size_t)(k + u) * Bp];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n0 + j < N) {
+                const float4 w = *reinterpret_cast<const float4*>(W + (size_t)j * K + k);      // wave-uniform address
+                acc[j] += x[0] * w.x + x[1] * w.y + x[2] * w.z + x[3] * w.w;
+            }
+        }
+    }
+    if (b < Bn)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n0 + j < N) Y[(size_t)b * ldy + n0 + j] = acc[j] + bias[n0 + j];
+}
+
 // dW[n][k] = sum_b dY[b][n] * act(X[b][k]);  db[n] = sum_b dY[b][n]
 __global__ __launch_bounds__(256) void lin_bwd_w_kernel(const float* __restrict__ dY, int ldy, const float* __restrict__ X, int ldx, int Bn, int K, int N,
                                                         int act, float* __restrict__ dW, float* __restrict__ db, size_t dystride, size_t wstride, size_t bstride) {
@@ -1317,6 +1356,7 @@ struct hd_trainer {
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
     int slot_stage_of_block(int i) const { return (nres - 1 - i) * std::min(4, nres) / nres; }
+    float *temb_act = nullptr, *temb_actT = nullptr; int Bp = 0;      // act(temb) and its transpose ([tdim][Bp], Bp = B rounded up to 64): the FiLM projections' input
     void* fjobs_dev = nullptr; int fjobs_n = 0, ftiles = 0;    // hicedrn: the job table of prep_filters_kernel (every block's two packed images in one launch)
     int objective = 0;                    // hd_train_set_objective: what the network's output is compared with (0 noise, 1 x_start, 2 v)
     float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
@@ -1513,6 +1553,8 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->per = (float*)need(dev_alloc<float>(t, 2 * B));
     t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
+    t->Bp = (B + 63) / 64 * 64;
+    t->temb_act = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->temb_actT = (float*)need(dev_alloc<float>(t, (size_t)t->Bp * t->tdim));
     t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));   // sized for the wider form
     t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     const int nchunk = (S * S + 63) / 64;
@@ -1653,8 +1695,16 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
     hipLaunchKernelGGL(lin_fwd_kernel, dim3((TD + 3) / 4), dim3(256), 0, st, tr->h1pre, TD, params + tr->o_t3w, params + tr->o_t3b, B, TD, TD, 2, tr->temb, TD, (size_t)0, (size_t)0, (size_t)0);
     const size_t lstride = n > 1 ? tr->o_mlp_w[1] - tr->o_mlp_w[0] : 0;        // every block's slots have the same sizes: a constant stride
     // non-SR3: Linear(SiLU(temb)) -> (scale, shift) (src/model/hicedrn_Diff.py:185-199); SR3: Linear(temb) -> shift (hicedrn_sr3_Diff.py:167-183)
-    hipLaunchKernelGGL(lin_fwd_kernel, dim3((FW + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, FW, sr3 ? 0 : 1,
-                       tr->film, FW, lstride, lstride, (size_t)B * FW);
+    static const bool film_old = getenv("HICDIFF_TRAIN_FILM_LIN_OLD") != nullptr;      // A/B: round 2's one-wave-per-(column, sample) kernels with the activation inside
+    const bool film_t = !film_old && TD % 4 == 0;
+    if (film_t) {
+        hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)(((size_t)tr->Bp * TD + 255) / 256)), dim3(256), 0, st, tr->temb, B, TD, sr3 ? 0 : 1, tr->Bp, tr->temb_act, tr->temb_actT);
+        hipLaunchKernelGGL(lin_fwd_t_kernel, dim3((FW + 15) / 16, n, tr->Bp / 64), dim3(256), 0, st, tr->temb_actT, tr->Bp, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B,
+                           TD, FW, tr->film, FW, lstride, lstride, (size_t)B * FW);
+    } else {
+        hipLaunchKernelGGL(lin_fwd_kernel, dim3((FW + 3) / 4, n), dim3(256), 0, st, tr->temb, TD, params + tr->o_mlp_w[0], params + tr->o_mlp_b[0], B, TD, FW, sr3 ? 0 : 1,
+                           tr->film, FW, lstride, lstride, (size_t)B * FW);
+    }
     TR_TRY(check_launch("time/film forward"));
     static const bool film_pass = getenv("HICDIFF_TRAIN_FILM_PASS") != nullptr;      // A/B: the separate FiLM + SiLU pass of round 2
     const bool film_in_epilogue = !film_pass;
@@ -1747,8 +1797,9 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
             // the stage's blocks are i .. hi: their FiLM projections (Linear(SiLU(temb)) per block) in one launch, then the stage's event
             int hi = i;
             while (hi + 1 < n && tr->slot_stage_of_block(hi + 1) == tr->block_stage_end[i]) ++hi;
-            hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, FW, hi - i + 1), dim3(256), 0, st, tr->dfilm + (size_t)i * B * FW, FW, tr->temb, TD, B, TD, FW,
-                               sr3 ? 0 : 1, grads + tr->o_mlp_w[i], grads + tr->o_mlp_b[i], (size_t)B * FW, lstride, lstride);
+            hipLaunchKernelGGL(lin_bwd_w_kernel, dim3((TD + 255) / 256, FW, hi - i + 1), dim3(256), 0, st, tr->dfilm + (size_t)i * B * FW, FW,
+                               film_t ? tr->temb_act : tr->temb, TD, B, TD, FW, film_t ? 0 : (sr3 ? 0 : 1), grads + tr->o_mlp_w[i], grads + tr->o_mlp_b[i],
+                               (size_t)B * FW, lstride, lstride);
             TR_TRY(check_launch("film projection wgrad"));
             stage_done(tr, tr->block_stage_end[i], st);
         }
