@@ -18,6 +18,10 @@ static int launch_mode(ConvLaunch& L, hipStream_t st) {
                 case 1: return need <= 3 ? launch_one(K32(2, 2, 2, 1, 3, 9), L, st) : launch_one(K32(2, 2, 2, 1, 5, 9), L, st);
                 case 2: return launch_one(K32(4, 1, 2, 2, 6, 9), L, st);
                 default:
+                    if (MODE == IN_NONE && (L.k.ep & EP_FILM_SILU_BWD)) {        // training: the data gradient through FiLM + SiLU (its own instantiations)
+                        if (L.k.plain) return launch_one(conv_igemm_bf16x3_fbwd_kernel<4, 2, 2, 2, 32, 3, IN_NONE, 9, true>, hd_prof_is_on() ? "conv_igemm_bf16_kernel<4, 2, 2, 2, 32, 3, 0, 9> (FiLM bwd)" : nullptr, L, st, 512);
+                        return launch_one(conv_igemm_bf16x3_fbwd_kernel<4, 2, 2, 2, 32, 3, IN_NONE, 9, false>, hd_prof_is_on() ? "conv_igemm_bf16x3_kernel<4, 2, 2, 2, 32, 3, 0, 9> (FiLM bwd)" : nullptr, L, st, 512);
+                    }
                     if (MODE == IN_NONE && L.k.plain)
                         return launch_one(conv_igemm_bf16_kernel<4, 2, 2, 2, 32, 3, IN_NONE, 9>, hd_prof_is_on() ? "conv_igemm_bf16_kernel<4, 2, 2, 2, 32, 3, 0, 9>" : nullptr, L, st, 512);
                     return launch_one(K32(4, 2, 2, 2, 3, 9), L, st, 512);

@@ -127,7 +127,7 @@ constexpr bool conv_cap3() { return HD_CK16_CAP3 && NTAPS == 9 && CK == 16 && WM
 #ifndef HD_CONV_XD2
 #define HD_CONV_XD2 1     // any-filter kernels: two activation prefetch register sets (0: one, the round-2 form; A/B builds)
 #endif
-template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN, bool FBWD = false>
 __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr bool M16 = CK == 32 && NTAPS == 9 && HD_MFMA16;   // 16 x 16 x 32 MFMA tiles (one instruction covers the whole 32-channel slice); the 1x1 kernels measured 5-12 % slower on it
@@ -644,7 +644,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 #ifdef HD_STAMPS
     const unsigned long long st_epi = HD_STAMP();
 #endif
-    conv_epilogue<BM, BN, TM, TN, NT>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
+    conv_epilogue<BM, BN, TM, TN, NT, FBWD>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
 #ifdef HD_STAMPS
     if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
         unsigned hwid;
@@ -667,6 +667,11 @@ __global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>()
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(ConvKArgs p) {
     conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, true>(p);
+}
+// training only: the same bodies with the EP_FILM_SILU_BWD epilogue mode compiled in (PLAIN: the bf16 option's one-product form)
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_fbwd_kernel(ConvKArgs p) {
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, PLAIN, true>(p);
 }
 
 template <typename K>

@@ -213,7 +213,9 @@ __device__ __forceinline__ void gn_direct_finalize(const GnFinArgs& f, int b, in
     f.A[i] = a; f.Bv[i] = bb;
 }
 
-template <int BM, int BN, int TM, int TN, int NT, typename Acc>
+// FBWD: the instantiation carries the training-only EP_FILM_SILU_BWD mode (one kernel of its own, conv_igemm_bf16x3_fbwd_kernel: compiled into the
+// sampler's kernels it cost hicedrn64 1.8 % and tipped the register-capped dominant unet64 kernel into scratch -- measured, A/B on one box).
+template <int BM, int BN, int TM, int TN, int NT, bool FBWD = false, typename Acc>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, Acc& acc, const int* rowpix,
                                               const int* rowb, float* stage) {
     constexpr bool M16 = sizeof(acc[0][0]) == 16;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         // NPASS passes waited out most of an HBM round trip -- the 1x1 shortcut at 64 x 64 spent two thirds of a workgroup's life there
         // (3.9 TB/s with the residual against 5.0 without).  Rows past the tile read pixel 0 (never used).
         float4 rr_all[NPASS];
-        const bool pre_res = vec && nvalid > 0 && (p.ep & (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES)) != 0;
+        const bool pre_res = vec && nvalid > 0 && (p.ep & (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES | (FBWD ? EP_FILM_SILU_BWD : 0))) != 0;
         if (pre_res) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -378,11 +380,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 // load them once instead of once per pass (vmcnt retires in order: every load in the pass loop is a wait on the stores
                 // and loads issued before it).
                 const bool one_b = p.TB == 1;
+                const bool film_bwd = FBWD && (p.ep & EP_FILM_SILU_BWD) != 0;
+                const bool has_scale = (p.ep & EP_FILM_SILU) || (film_bwd && p.epScale);
+                constexpr int FILM_EPS = EP_FILM_SILU | EP_ADD_SILU | (FBWD ? EP_FILM_SILU_BWD : 0);
                 if (one_b) {
-                    if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                    if (p.ep & FILM_EPS) {
                         const int fo = t.b0 * p.ep_bstride + n;
                         n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
-                        if (p.ep & EP_FILM_SILU) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
+                        if (has_scale) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                     }
                     if (p.ep & EP_RES_AFFINE_SILU) {
                         const int fo = t.b0 * p.res_bstride + n;
@@ -393,10 +398,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 auto fetch = [&](int pass) {
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
-                    if (!one_b && (p.ep & (EP_FILM_SILU | EP_ADD_SILU))) {
+                    if (!one_b && (p.ep & FILM_EPS)) {
                         const int fo = rowb[m] * p.ep_bstride + n;
                         n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
-                        if (p.ep & EP_FILM_SILU) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
+                        if (has_scale) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                     }
                     if (!one_b && (p.ep & EP_RES_AFFINE_SILU)) {
                         const int fo = rowb[m] * p.res_bstride + n;
@@ -415,7 +420,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     if (pass + 1 < NPASS) fetch(pass + 1);
                     const float4 a4 = *reinterpret_cast<const float4*>(stage + lr * EP + cq * 4);
                     float v[4] = {a4.x + bias[0], a4.y + bias[1], a4.z + bias[2], a4.w + bias[3]};
-                    if (p.gn_part && pix >= 0) {          // (no GroupNorm follows the shortcut / projection convolutions that take this path: skip the sums)
+                    if (film_bwd) {
+                        // training: the gradient through silu(u (scale + 1) + shift), and the FiLM row's own gradient sums in the GroupNorm sums' place
+                        const float uu[4] = {rr.x, rr.y, rr.z, rr.w}, scv[4] = {sc.x + 1.f, sc.y + 1.f, sc.z + 1.f, sc.w + 1.f}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float vv = uu[j] * scv[j] + shv[j];
+                            const float sg = 1.f / (1.f + __expf(-vv));
+                            const float dv = p.alpha * v[j] * (sg * (1.f + vv * (1.f - sg)));
+                            const float a_ = pix >= 0 ? dv * uu[j] : 0.f, b_ = pix >= 0 ? dv : 0.f;
+                            s1[0][j] += up ? 0.f : a_; s2[0][j] += up ? 0.f : b_; s1[1][j] += up ? a_ : 0.f; s2[1][j] += up ? b_ : 0.f;
+                            v[j] = dv * scv[j];
+                        }
+                    } else if (p.gn_part && pix >= 0) {          // (no GroupNorm follows the shortcut / projection convolutions that take this path: skip the sums)
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = v[j], lo = up ? 0.f : x, hi = up ? x : 0.f;

@@ -291,6 +291,13 @@ bool conv_gn_direct(const ConvArgs& a) {
     return (a.H + pl.g.TH - 1) / pl.g.TH == 1 && (a.W + pl.g.TW - 1) / pl.g.TW == 1;
 }
 
+// EP_FILM_SILU_BWD (training) is compiled into the 8-wave 256 x 128 tile only: can this launch take it?
+bool conv_film_bwd_ok(const ConvArgs& a) {
+    if (a.ep != EP_FILM_SILU_BWD || !a.res || !a.epShift || a.cw.Cout % 4 || conv_uses_winograd(a) || a.precision != HD_PREC_BF16X3) return false;
+    const ConvPlan pl = plan_conv(a);
+    return pl.fast && pl.cfg == 3 && pl.ck == 32 && a.in_mode == IN_NONE;
+}
+
 int conv_gn_slots(const ConvArgs& a) {
     if (conv_uses_winograd(a)) return (a.H / 16) * (a.W / 16);   // one slot per 16 x 16 block
     if (conv_splitk(a) > 1) return 1;             // one slot per sample, written by the split-K reduce (which sees the finished output)
@@ -325,6 +332,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     if ((long long)a.B * a.H * a.W * a.cw.Cout >= (1LL << 31)) { hd_set_error("conv: output tensors of 2^31 elements or more are not supported (cut the batch)"); return -1; }
     if (a.pre_out && (!(a.ep & (EP_FILM_SILU | EP_ADD_SILU)) || a.cw.Cout % 4 || conv_uses_winograd(a) || (a.splitk_ws && conv_splitk(a) > 1))) {
         hd_set_error("conv: pre_out rides on the FiLM / additive SiLU epilogue of an unsplit direct convolution with Cout % 4 == 0"); return -1;
+    }
+    if ((a.ep & EP_FILM_SILU_BWD) && !conv_film_bwd_ok(a)) {
+        hd_set_error("conv: the FiLM + SiLU backward epilogue stands alone, needs u (res) and the shift row, and exists in the 8-wave 3x3 tile only"); return -1;
     }
     if (conv_uses_winograd(a)) {
         if (k.Cin != a.cw.Cin) { hd_set_error("conv: channel counts do not match the packed weight"); return -1; }

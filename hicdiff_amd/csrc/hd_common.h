@@ -36,6 +36,9 @@ enum EpFlags {
     EP_ADD_SILU = 2,       // v = silu(v + shift[b][n])                            (hicedrn SR3 block)
     EP_RES = 4,            // v = alpha * v + res[pix][n]
     EP_RES_AFFINE_SILU = 8, // v = v + silu(res[pix][n] * resA[b][n] + resB[b][n]) (UNet block tail through res_conv)
+    EP_FILM_SILU_BWD = 64, // training, data gradient through a = silu(u (scale + 1) + shift): v is dL/da / alpha; with u = res[pix][n]:
+                           // dv = alpha v silu'(u (scale + 1) + shift), out = dv (scale + 1) (epScale null: scale = 0); with gn_part the
+                           // per-channel sums over the tile's pixels (sum dv u, sum dv) go where the GroupNorm sums would (d scale, d shift)
     EP_LN_STATS = 32,      // also write the channel-LayerNorm statistics (mean, rstd) of the final row to ln_stats_out[pix]; needs Cout == tile width
     EP_LN_RES = 16         // v = LayerNorm_channels(v) * ep_ln_g[n] + res[pix][n]   (LinearAttention to_out tail, src/hicdiff.py:207-210,64-70); needs Cout == tile width
 };
@@ -107,6 +110,7 @@ int hd_prof_collect(const char** names, double* ms, double* flops, double* bytes
 int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out = nullptr);
 bool conv_gn_direct(const ConvArgs& a);   // with a.gn_fin set: launch_conv writes the GroupNorm affine itself (no gn_finalize launch needed)
 int conv_splitk(const ConvArgs& a);    // K splits the planner wants for this convolution (1: none); a.precision must be set
+bool conv_film_bwd_ok(const ConvArgs& a);   // can this launch run the EP_FILM_SILU_BWD epilogue (8-wave 3x3 tile only)?
 int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials would use (0: not fusable)
 
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,

@@ -885,6 +885,20 @@ __global__ __launch_bounds__(256) void film_silu_bwd_kernel(float* __restrict__ 
     }
 }
 
+// d film row of one block from the convolution epilogue's per-tile sums (EP_FILM_SILU_BWD): part [B][slots][C][2] = (sum dv u, sum dv) ->
+// out [B][FW] = [d scale | d shift] (FW == C: d shift alone), slots added in order
+__global__ __launch_bounds__(256) void film_part_reduce_kernel(const float* __restrict__ part, int slots, int C, int FW, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= C) return;
+    float a = 0.f, q = 0.f;
+    for (int s = 0; s < slots; ++s) {
+        const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)b * slots + s) * C + c) * 2);
+        a += v.x; q += v.y;
+    }
+    if (FW == 2 * C) out[(size_t)b * FW + c] = a;
+    out[(size_t)b * FW + (FW - C) + c] = q;
+}
+
 // out[batch][col] (+)= scale * sum_row in[batch][row][col]
 __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ in, int nrows, int ncols, float scale, int accumulate,
                                                        float* __restrict__ out) {
@@ -1356,6 +1370,7 @@ struct hd_trainer {
     std::vector<hipEvent_t> stage_ev;
     std::vector<int> block_stage_end;     // hicedrn: stage whose last block is i (recorded after block i's backward), or -1
     int slot_stage_of_block(int i) const { return (nres - 1 - i) * std::min(4, nres) / nres; }
+    float* film_part = nullptr;           // [B][tiles per sample][F][2]: the data-gradient convolution's FiLM sums (EP_FILM_SILU_BWD)
     float *temb_act = nullptr, *temb_actT = nullptr; int Bp = 0;      // act(temb) and its transpose ([tdim][Bp], Bp = B rounded up to 64): the FiLM projections' input
     void* fjobs_dev = nullptr; int fjobs_n = 0, ftiles = 0;    // hicedrn: the job table of prep_filters_kernel (every block's two packed images in one launch)
     int objective = 0;                    // hd_train_set_objective: what the network's output is compared with (0 noise, 1 x_start, 2 v)
@@ -1554,6 +1569,7 @@ int hd_train_create(hd_trainer** out, int device, const hd_arch_desc* a, int B, 
     t->emb = (float*)need(dev_alloc<float>(t, (size_t)B * F)); t->h1pre = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->temb = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
     t->Bp = (B + 63) / 64 * 64;
+    t->film_part = (float*)need(dev_alloc<float>(t, (size_t)B * ((S * S + 63) / 64) * F * 2));      // (at most one tile per 64 pixels)
     t->temb_act = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->temb_actT = (float*)need(dev_alloc<float>(t, (size_t)t->Bp * t->tdim));
     t->film = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F)); t->dfilm = (float*)need(dev_alloc<float>(t, (size_t)n * B * 2 * F));   // sized for the wider form
     t->dst = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim)); t->dh1 = (float*)need(dev_alloc<float>(t, (size_t)B * t->tdim));
@@ -1777,10 +1793,25 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
             TR_TRY(wgrad(tr, 0.1f, false, dW, st));
             TR_TRY(colsum(tr, 0.1f, false, db, st));
         }
-        TR_TRY(conv3(tr, tr->bwd[i], dx, da, 0, 1.f, nullptr, st));              // dL/da / 0.1
-        hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, FW, HW, F, 64, 0.1f, tr->fpart);
-        hipLaunchKernelGGL(sum_rows_kernel, dim3((FW + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, FW, 1.f, 0, tr->dfilm + (size_t)i * B * FW);
-        TR_TRY(check_launch("film_silu_bwd"));
+        // dL/da / 0.1 by the data-gradient convolution, then through a = silu(film(u)): in the convolution's epilogue where its tiling allows the
+        // per-sample sums (one sample per tile), else as round 2's separate pass (3 x 268 MB per block at 64 tiles)
+        ConvArgs dg;
+        dg.in0 = dx; dg.C0 = F; dg.B = B; dg.H = S; dg.W = S; dg.IH = S; dg.IW = S; dg.stride = 1; dg.pad = 1; dg.cw = tr->bwd[i]; dg.out = da;
+        dg.precision = HD_PREC_BF16X3; dg.plain_bf16 = tr->plain;
+        dg.ep = EP_FILM_SILU_BWD; dg.alpha = 0.1f; dg.res = tr->U[i]; dg.epScale = FW > F ? film : nullptr; dg.epShift = film + (FW - F); dg.ep_bstride = FW;
+        dg.gn_part = tr->film_part;
+        static const bool film_bwd_pass = getenv("HICDIFF_TRAIN_FILM_BWD_PASS") != nullptr;       // A/B: round 2's separate pass
+        const int fslots = film_bwd_pass || !conv_film_bwd_ok(dg) ? 0 : conv_gn_slots(dg);
+        if (fslots > 0 && (size_t)fslots <= (size_t)(HW + 63) / 64) {
+            TR_TRY(launch_conv(dg, st, nullptr));
+            hipLaunchKernelGGL(film_part_reduce_kernel, dim3((F + 255) / 256, B), dim3(256), 0, st, tr->film_part, fslots, F, FW, tr->dfilm + (size_t)i * B * FW);
+            TR_TRY(check_launch("film_part_reduce"));
+        } else {
+            TR_TRY(conv3(tr, tr->bwd[i], dx, da, 0, 1.f, nullptr, st));
+            hipLaunchKernelGGL(film_silu_bwd_kernel, dim3(nchunk, B), dim3(256), 0, st, da, tr->U[i], film, FW, HW, F, 64, 0.1f, tr->fpart);
+            hipLaunchKernelGGL(sum_rows_kernel, dim3((FW + 255) / 256, B), dim3(256), 0, st, tr->fpart, nchunk, FW, 1.f, 0, tr->dfilm + (size_t)i * B * FW);
+            TR_TRY(check_launch("film_silu_bwd"));
+        }
         // first use: u = conv(x)
         if (direct) {
             TR_TRY(tr->wg.run_direct(tr->X[i], F, nullptr, 0, da, F, 3, dW, db, st, nullptr, nullptr, nullptr, 0, 1.f, true, 0, 0.f, plain));
