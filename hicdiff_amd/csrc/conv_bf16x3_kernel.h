@@ -644,7 +644,11 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
 #ifdef HD_STAMPS
     const unsigned long long st_epi = HD_STAMP();
 #endif
-    conv_epilogue<BM, BN, TM, TN, NT, FBWD>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
+    // epilogue modes an instantiation can be asked for (conv_host.hip: conv_ep_mask): the unrolled-tap kernels serve the GroupNorm'd / FiLM'd /
+    // residual 3x3 layers, the any-filter kernels the 1x1 projections with their LayerNorm and GroupNorm-apply tails; what a family never
+    // sees is compiled out of it (the 8-wave kernel: 186.0 -> 184.9 ms per hicedrn64 step, A/B on one box)
+    constexpr int EPMASK = NTAPS == 9 ? (EP_FILM_SILU | EP_ADD_SILU | EP_RES | EP_FILM_SILU_BWD) : (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES | EP_LN_STATS);
+    conv_epilogue<BM, BN, TM, TN, NT, FBWD, EPMASK>(p, t, acc, rowpix, rowb, reinterpret_cast<float*>(Ws));
 #ifdef HD_STAMPS
     if (tid == 0 && blockIdx.x < 4096 && blockIdx.y == 0) {
         unsigned hwid;

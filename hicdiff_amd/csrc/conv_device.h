@@ -215,10 +215,12 @@ __device__ __forceinline__ void gn_direct_finalize(const GnFinArgs& f, int b, in
 
 // FBWD: the instantiation carries the training-only EP_FILM_SILU_BWD mode (one kernel of its own, conv_igemm_bf16x3_fbwd_kernel: compiled into the
 // sampler's kernels it cost hicedrn64 1.8 % and tipped the register-capped dominant unet64 kernel into scratch -- measured, A/B on one box).
-template <int BM, int BN, int TM, int TN, int NT, bool FBWD = false, typename Acc>
+template <int BM, int BN, int TM, int TN, int NT, bool FBWD = false, int EPMASK = -1, typename Acc>
 __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx& t, Acc& acc, const int* rowpix,
                                               const int* rowb, float* stage) {
     constexpr bool M16 = sizeof(acc[0][0]) == 16;
+    // EPMASK: the epilogue modes this instantiation can be asked for (the host never sends others: plan_conv); the rest compiles out
+    const int ep = p.ep & EPMASK;
     // The tile is staged in TM rounds of BM/TM rows (round tm holds, for every wave-row wm, its rows
     // tm*32..tm*32+31), so the staging area is BM/TM x (BN+4) floats and does not set the LDS footprint.
     constexpr int EP = BN + 4, CQ = BN / 4, RPP = NT / CQ, RB = BM / TM, NPASS = RB / RPP, WMN = BM / (32 * TM);
@@ -249,7 +251,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         // NPASS passes waited out most of an HBM round trip -- the 1x1 shortcut at 64 x 64 spent two thirds of a workgroup's life there
         // (3.9 TB/s with the residual against 5.0 without).  Rows past the tile read pixel 0 (never used).
         float4 rr_all[NPASS];
-        const bool pre_res = vec && nvalid > 0 && (p.ep & (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES | (FBWD ? EP_FILM_SILU_BWD : 0))) != 0;
+        const bool pre_res = vec && nvalid > 0 && (ep & (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES | (FBWD ? EP_FILM_SILU_BWD : 0))) != 0;
         if (pre_res) {
 #pragma unroll
             for (int pass = 0; pass < NPASS; ++pass) {
@@ -296,7 +298,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
         e1 = __builtin_readcyclecounter(); e_bar += e1 - e0;
 #endif
         if (nvalid > 0 && !(p.ablate & 128)) {
-            if (p.ep & EP_LN_RES) {
+            if (ep & EP_LN_RES) {
                 // Whole rows live in this workgroup (Cout == BN, checked by the launcher): channel LayerNorm of the
                 // row (biased variance, eps 1e-5: src/hicdiff.py:99-108), gain, + residual.  A row is held by CQ
                 // consecutive lanes (4 channels each); sums travel by xor shuffles inside that group.
@@ -321,7 +323,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                     const f32x4 o4 = {v[0] * rs * g4.x + rr.x, v[1] * rs * g4.y + rr.y, v[2] * rs * g4.z + rr.z, v[3] * rs * g4.w + rr.w};
                     if (pix >= 0) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
                 }
-            } else if (p.ep == 0 && vec) {
+            } else if (ep == 0 && vec) {
                 // Fast path (every GroupNorm'd conv): no global load in the loop.  vmcnt retires in issue order, so a
                 // loop that mixes loads with stores makes every load wait for the previous pass's STORE round trip
                 // (measured: half of the kernel on the 64-channel full-resolution layers); here stores just stream.
@@ -380,16 +382,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 // load them once instead of once per pass (vmcnt retires in order: every load in the pass loop is a wait on the stores
                 // and loads issued before it).
                 const bool one_b = p.TB == 1;
-                const bool film_bwd = FBWD && (p.ep & EP_FILM_SILU_BWD) != 0;
-                const bool has_scale = (p.ep & EP_FILM_SILU) || (film_bwd && p.epScale);
+                const bool film_bwd = FBWD && (ep & EP_FILM_SILU_BWD) != 0;
+                const bool has_scale = (ep & EP_FILM_SILU) || (film_bwd && p.epScale);
                 constexpr int FILM_EPS = EP_FILM_SILU | EP_ADD_SILU | (FBWD ? EP_FILM_SILU_BWD : 0);
                 if (one_b) {
-                    if (p.ep & FILM_EPS) {
+                    if (ep & FILM_EPS) {
                         const int fo = t.b0 * p.ep_bstride + n;
                         n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
                         if (has_scale) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                     }
-                    if (p.ep & EP_RES_AFFINE_SILU) {
+                    if (ep & EP_RES_AFFINE_SILU) {
                         const int fo = t.b0 * p.res_bstride + n;
                         n_ra = *reinterpret_cast<const float4*>(p.resA + fo);
                         n_rb = *reinterpret_cast<const float4*>(p.resB + fo);
@@ -398,12 +400,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                 auto fetch = [&](int pass) {
                     const int lr = pass * RPP + rg;
                     const int m = (lr >> 5) * 32 * TM + tm * 32 + (lr & 31);
-                    if (!one_b && (p.ep & FILM_EPS)) {
+                    if (!one_b && (ep & FILM_EPS)) {
                         const int fo = rowb[m] * p.ep_bstride + n;
                         n_sh = *reinterpret_cast<const float4*>(p.epShift + fo);
                         if (has_scale) n_sc = *reinterpret_cast<const float4*>(p.epScale + fo);
                     }
-                    if (!one_b && (p.ep & EP_RES_AFFINE_SILU)) {
+                    if (!one_b && (ep & EP_RES_AFFINE_SILU)) {
                         const int fo = rowb[m] * p.res_bstride + n;
                         n_ra = *reinterpret_cast<const float4*>(p.resA + fo);
                         n_rb = *reinterpret_cast<const float4*>(p.resB + fo);
@@ -439,23 +441,23 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                             s1[0][j] += lo; s2[0][j] = __builtin_fmaf(lo, lo, s2[0][j]); s1[1][j] += hi; s2[1][j] = __builtin_fmaf(hi, hi, s2[1][j]);   // explicit fma: see the fast path
                         }
                     }
-                    if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                    if (ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                         if (p.pre_out && pix >= 0) *reinterpret_cast<f32x4*>(p.pre_out + (size_t)pix * p.Cout + n) = f32x4{v[0], v[1], v[2], v[3]};
-                        if (p.ep & EP_FILM_SILU) {
+                        if (ep & EP_FILM_SILU) {
                             v[0] = v[0] * (sc.x + 1.f) + sh.x; v[1] = v[1] * (sc.y + 1.f) + sh.y;
                             v[2] = v[2] * (sc.z + 1.f) + sh.z; v[3] = v[3] * (sc.w + 1.f) + sh.w;
                         } else { v[0] += sh.x; v[1] += sh.y; v[2] += sh.z; v[3] += sh.w; }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = silu_f(v[j]);
                     }
-                    if (p.ep & EP_RES) { v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w; }
-                    if (p.ep & EP_RES_AFFINE_SILU) {
+                    if (ep & EP_RES) { v[0] = p.alpha * v[0] + rr.x; v[1] = p.alpha * v[1] + rr.y; v[2] = p.alpha * v[2] + rr.z; v[3] = p.alpha * v[3] + rr.w; }
+                    if (ep & EP_RES_AFFINE_SILU) {
                         v[0] += silu_f(rr.x * ra.x + rb.x); v[1] += silu_f(rr.y * ra.y + rb.y);
                         v[2] += silu_f(rr.z * ra.z + rb.z); v[3] += silu_f(rr.w * ra.w + rb.w);
                     }
                     const f32x4 o4 = {v[0], v[1], v[2], v[3]};
                     if (pix >= 0 && !(p.ablate & 1)) *reinterpret_cast<f32x4*>(p.out + (size_t)pix * p.Cout + n) = o4;
-                    if (p.ep & EP_LN_STATS) {
+                    if (ep & EP_LN_STATS) {
                         // statistics of the finished row for the PreNorm of the attention block that consumes it (Cout == BN:
                         // the row is the CQ consecutive lanes of this pass); same two-pass form as ln_stats_kernel
                         float sm = (v[0] + v[1]) + (v[2] + v[3]);
@@ -483,13 +485,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvKArgs& p, const TileCtx&
                         if (j >= nvalid) break;
                         float x = v[j];
                         s1[0][j] += x; s2[0][j] += x * x;
-                        if (p.ep & (EP_FILM_SILU | EP_ADD_SILU)) {
+                        if (ep & (EP_FILM_SILU | EP_ADD_SILU)) {
                             const int fo = rowb[m] * p.ep_bstride + n + j;
-                            x = (p.ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
+                            x = (ep & EP_FILM_SILU) ? x * (p.epScale[fo] + 1.f) + p.epShift[fo] : x + p.epShift[fo];
                             x = silu_f(x);
                         }
-                        if (p.ep & EP_RES) x = p.alpha * x + p.res[o + j];
-                        if (p.ep & EP_RES_AFFINE_SILU) {
+                        if (ep & EP_RES) x = p.alpha * x + p.res[o + j];
+                        if (ep & EP_RES_AFFINE_SILU) {
                             const int fo = rowb[m] * p.res_bstride + n + j;
                             x += silu_f(p.res[o + j] * p.resA[fo] + p.resB[fo]);
                         }

@@ -333,6 +333,13 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     if (a.pre_out && (!(a.ep & (EP_FILM_SILU | EP_ADD_SILU)) || a.cw.Cout % 4 || conv_uses_winograd(a) || (a.splitk_ws && conv_splitk(a) > 1))) {
         hd_set_error("conv: pre_out rides on the FiLM / additive SiLU epilogue of an unsplit direct convolution with Cout % 4 == 0"); return -1;
     }
+    {   // the bf16x3 kernel families are compiled with the epilogue modes their layers use (conv_bf16x3_kernel.h EPMASK)
+        const bool t9 = a.cw.KH == 3 && a.cw.KW == 3 && a.in_mode != IN_LAYERNORM && a.in_mode != IN_SOFTMAX32;
+        const int mask = t9 ? (EP_FILM_SILU | EP_ADD_SILU | EP_RES | EP_FILM_SILU_BWD) : (EP_RES | EP_RES_AFFINE_SILU | EP_LN_RES | EP_LN_STATS);
+        if (a.precision == HD_PREC_BF16X3 && a.cw.wsplit && (a.ep & ~mask)) {
+            hd_set_error("conv: this epilogue mode is not compiled into the split-bf16 kernel family of this filter shape"); return -1;
+        }
+    }
     if ((a.ep & EP_FILM_SILU_BWD) && !conv_film_bwd_ok(a)) {
         hd_set_error("conv: the FiLM + SiLU backward epilogue stands alone, needs u (res) and the shift row, and exists in the 8-wave 3x3 tile only"); return -1;
     }
