@@ -341,6 +341,8 @@ def main():
     ap.add_argument("--total-tiles", type=int, default=None,
                     help="strong-scaling form (BASELINE configs[3]: 256 hicedrn tiles sharded over the node): the job is this many tiles in all, "
                          "total/N per GPU; reported with \"scaling\": \"strong\"")
+    ap.add_argument("--chains", type=int, default=None, choices=[1, 2],
+                    help="force one whole-batch chain or two half-batch chains per GPU (default: the library's rule, two from 512 k pixels per step on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
     ap.add_argument("--full-chain", action="store_true", help="time a whole chain: --steps becomes 1000 (t = 999 .. 0)")
@@ -382,11 +384,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    eng = net.engine(device)
+    if args.chains is not None:
+        eng.set_chains(args.chains)
+    chains = eng.chains_for(B, S)
+
     def run_steps(n, t):
-        """n reverse steps starting at timestep t (wrapping into a new chain below 0); returns the next t."""
-        for _ in range(n):
-            diff._step_inplace(img, t, cond)
-            t = t - 1 if t > 0 else T_CHAIN - 1
+        """n reverse steps starting at timestep t (wrapping into a new chain below 0); returns the next t.  The steps run inside the
+        sampler's chain bracket (hicdiff_amd/_diffusion.py:_ancestral): the state meets this stream at the ends only."""
+        with eng.chain(B, S):
+            for _ in range(n):
+                diff._step_inplace(img, t, cond, eng=eng)
+                t = t - 1 if t > 0 else T_CHAIN - 1
         return t
 
     # warm-up steps run at the END of a previous chain so that a --steps 1000 region is exactly t = 999 .. 0
@@ -486,6 +495,7 @@ def main():
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
                                    f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
                        "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
+                       "chains": chains,
                        **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
                        "timed_region": ("one whole chain, t = 999 .. 0" if args.steps == T_CHAIN else
                                         f"{args.steps} consecutive steps from t = 999 (every step costs the same; see `sustained`)")},

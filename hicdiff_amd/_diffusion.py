@@ -9,6 +9,7 @@ schedule buffers and keeps the reference's method names, argument meaning and as
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from collections import namedtuple
 from typing import Optional
@@ -228,10 +229,12 @@ class DiffusionCore(nn.Module):
             c.time_value = float(t_idx)
         return c
 
-    def _step_inplace(self, img, t_idx: int, cond, x0_out=None):
+    def _step_inplace(self, img, t_idx: int, cond, x0_out=None, eng=None):
         """img <- p_sample(img, t): one hd_ddpm_step call (eps-net + clamp + posterior + noise).  The three objectives differ only in the two
-        coefficients that turn the network's output into x0 (_x0_coefs)."""
-        eng = self.model.engine(img.device)
+        coefficients that turn the network's output into x0 (_x0_coefs).  `eng`: the engine a loop looked up once -- `model.engine()` compares
+        every parameter's (address, version) with the packed copy, 0.4 ms of host time that belongs to the chain, not to each step."""
+        if eng is None:
+            eng = self.model.engine(img.device)
         noise = None
         if t_idx > 0 and self.noise_source is not None:
             noise = self.noise_source.randn(img.shape).contiguous()
@@ -255,15 +258,22 @@ class DiffusionCore(nn.Module):
     def _device(self):
         return self.betas.device
 
+    def _bracket(self, eng, shape, free_running: bool):
+        """A chain bracket (Engine.chain) when nothing on the caller's stream has to see the state between steps: device noise, no
+        per-step copies.  Otherwise every step hands over to the caller's stream as before."""
+        return eng.chain(shape[0], shape[-1]) if free_running else contextlib.nullcontext()
+
     @torch.no_grad()
     def _ancestral(self, shape, cond, return_all_timesteps, first):
         device = self._device()
+        eng = self.model.engine(device)
         img = self._initial_noise(shape, device)
         imgs = [first if first is not None else img.clone()] if return_all_timesteps else None
-        for t in reversed(range(self.num_timesteps)):
-            self._step_inplace(img, t, cond)
-            if return_all_timesteps:       # upstream keeps all T+1 tensors alive (src/hicdiff.py:615); here only on request
-                imgs.append(img.clone())
+        with self._bracket(eng, shape, self.noise_source is None and not return_all_timesteps):
+            for t in reversed(range(self.num_timesteps)):
+                self._step_inplace(img, t, cond, eng=eng)
+                if return_all_timesteps:       # upstream keeps all T+1 tensors alive (src/hicdiff.py:615); here only on request
+                    imgs.append(img.clone())
         return img, imgs
 
     @torch.no_grad()
@@ -287,39 +297,45 @@ class DiffusionCore(nn.Module):
         finally:
             eng.set_precision(saved)
 
+    def _ddim_coef(self, time: int, time_next: int) -> L.HdDdpmCoef:
+        """Coefficients that make the fused step a DDIM step: x <- sqrt(a_next) x0 + sqrt(1 - a_next - sigma^2) eps + sigma z
+        (src/hicdiff.py:636-658)."""
+        h, eta = self._host, self.ddim_sampling_eta
+        ac = h["alphas_cumprod"]
+        c = L.HdDdpmCoef()
+        c.sqrt_recip_alphas_cumprod, c.sqrt_recipm1_alphas_cumprod = self._x0_coefs(time)
+        c.time_value = float(time)
+        c.posterior_mean_coef2 = 0.0
+        if time_next < 0:                      # last step: x_0 itself (src/hicdiff.py:642-645)
+            c.posterior_mean_coef1, c.eps_coef, c.sigma = 1.0, 0.0, 0.0
+            return c
+        a, an = ac[time], ac[time_next]
+        sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+        c.posterior_mean_coef1, c.eps_coef, c.sigma = float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
+        if self.objective != "pred_noise":
+            # the noise is derived from the CLIPPED x0 (model_predictions, src/hicdiff.py:571-580): eps = (R x - x0) / Rm1, so
+            # sqrt(a_next) x0 + k eps = (sqrt(a_next) - k / Rm1) x0 + (k R / Rm1) x -- the kernel's x0 and x terms, no output term
+            R, Rm1, k = float(h["sqrt_recip_alphas_cumprod"][time]), float(h["sqrt_recipm1_alphas_cumprod"][time]), c.eps_coef
+            c.posterior_mean_coef1, c.posterior_mean_coef2, c.eps_coef = c.posterior_mean_coef1 - k / Rm1, k * R / Rm1, 0.0
+        return c
+
     def _ddim_sample(self, shape, return_all_timesteps=False):
         """Each DDIM step is the same fused call as the ancestral step (hd_ddpm_step: eps-net + clamp + update + noise, hipGraph
-        replay with device noise) with other coefficients: x <- sqrt(a_next) x0 + sqrt(1 - a_next - sigma^2) eps + sigma z."""
+        replay with device noise) with other coefficients (_ddim_coef)."""
         shape = tuple(shape)
-        device, T, S, eta = self._device(), self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        device, T, S = self._device(), self.num_timesteps, self.sampling_timesteps
         times = list(reversed(torch.linspace(-1, T - 1, steps=S + 1).int().tolist()))
-        h = self._host
-        ac = h["alphas_cumprod"]
         eng = self.model.engine(device)
         img = self._initial_noise(shape, device)
         imgs = [img.clone()] if return_all_timesteps else None
-        for time, time_next in zip(times[:-1], times[1:]):
-            c = L.HdDdpmCoef()
-            c.sqrt_recip_alphas_cumprod, c.sqrt_recipm1_alphas_cumprod = self._x0_coefs(time)
-            c.time_value = float(time)
-            c.posterior_mean_coef2 = 0.0
-            noise = None
-            if time_next < 0:                      # last step: x_0 itself (src/hicdiff.py:642-645)
-                c.posterior_mean_coef1, c.eps_coef, c.sigma = 1.0, 0.0, 0.0
-            else:
-                a, an = ac[time], ac[time_next]
-                sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
-                c.posterior_mean_coef1, c.eps_coef, c.sigma = float(an.sqrt()), float((1 - an - sigma ** 2).sqrt()), float(sigma)
-                if self.objective != "pred_noise":
-                    # the noise is derived from the CLIPPED x0 (model_predictions, src/hicdiff.py:571-580): eps = (R x - x0) / Rm1, so
-                    # sqrt(a_next) x0 + k eps = (sqrt(a_next) - k / Rm1) x0 + (k R / Rm1) x -- the kernel's x0 and x terms, no output term
-                    R, Rm1, k = float(h["sqrt_recip_alphas_cumprod"][time]), float(h["sqrt_recipm1_alphas_cumprod"][time]), c.eps_coef
-                    c.posterior_mean_coef1, c.posterior_mean_coef2, c.eps_coef = c.posterior_mean_coef1 - k / Rm1, k * R / Rm1, 0.0
-                if self.noise_source is not None:      # the reference draws randn_like(img) at every such step, eta = 0 included
+        with self._bracket(eng, shape, self.noise_source is None and not return_all_timesteps):
+            for time, time_next in zip(times[:-1], times[1:]):
+                noise = None
+                if time_next >= 0 and self.noise_source is not None:      # the reference draws randn_like(img) at every such step, eta = 0 included
                     noise = self.noise_source.randn(shape).contiguous()
-            eng.ddpm_step(img, None, noise, c, None, seed=self.seed, tile_offset=self.tile_offset, step=time)
-            if return_all_timesteps:
-                imgs.append(img.clone())
+                eng.ddpm_step(img, None, noise, self._ddim_coef(time, time_next), None, seed=self.seed, tile_offset=self.tile_offset, step=time)
+                if return_all_timesteps:
+                    imgs.append(img.clone())
         ret = img if not return_all_timesteps else torch.stack(imgs, dim=1)
         return self.unnormalize(ret)
 
@@ -338,8 +354,10 @@ class DiffusionCore(nn.Module):
         assert x1.shape == x2.shape
         tb = torch.full((b,), t, device=x1.device, dtype=torch.long)
         img = ((1 - lam) * self.q_sample(x1, tb) + lam * self.q_sample(x2, tb)).contiguous()
-        for i in reversed(range(0, t)):
-            self._step_inplace(img, i, None)
+        eng = self.model.engine(img.device)
+        with self._bracket(eng, img.shape, self.noise_source is None):
+            for i in reversed(range(0, t)):
+                self._step_inplace(img, i, None, eng=eng)
         return img
 
     # -- forward process and loss ----------------------------------------------------------------

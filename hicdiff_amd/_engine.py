@@ -3,6 +3,7 @@ packed weights in step with the module's parameters, and exposes the hot-path ca
 tensors (torch is only the owner of device memory and streams here)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Optional
@@ -95,6 +96,27 @@ class Engine:
         """L.HD_PRECISION_F32 (exact fp32 MFMA) or L.HD_PRECISION_BF16X3 (default, split-bf16 x3)."""
         self._check(self.lib.hd_set_precision(self.ctx, int(mode)))
         self.precision = int(mode)
+
+    def set_chains(self, n: int):
+        """2: always cut a replayed step into two half-batch chains on two streams, 1: never, 0: the default (by the amount of work)."""
+        self._check(self.lib.hd_set_chains(self.ctx, int(n)))
+
+    def chains_for(self, B: int, S: int) -> int:
+        return int(self.lib.hd_chains_for(self.ctx, B, S))
+
+    @contextlib.contextmanager
+    def chain(self, B: int, S: int):
+        """The loop of a sampler (src/hicdiff.py:603-620) as a bracket: inside it the replayed steps meet the caller's stream only at the
+        first step and at the end, so the two half-batch chains of a large batch advance independently (hd_chain_begin / hd_chain_end).
+        The caller must leave the step tensors alone on its own stream until the bracket closes."""
+        self.reserve(B, S)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.hd_chain_begin(self.ctx, _stream()))
+        try:
+            yield self
+        finally:
+            with torch.cuda.device(self.device):
+                self._check(self.lib.hd_chain_end(self.ctx, _stream()))
 
     def workspace_bytes(self, B: int, S: int) -> int:
         out = C.c_size_t()

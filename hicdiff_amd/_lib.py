@@ -86,6 +86,10 @@ SYMBOLS = {
     "hd_profile_read": (C.c_int, [C.POINTER(HdProfileRow), C.c_int]),
     "hd_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_set_graphs": (C.c_int, [_P, C.c_int]),
+    "hd_set_chains": (C.c_int, [_P, C.c_int]),
+    "hd_chains_for": (C.c_int, [_P, C.c_int, C.c_int]),
+    "hd_chain_begin": (C.c_int, [_P, _P]),
+    "hd_chain_end": (C.c_int, [_P, _P]),
     "hd_randn": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, _P]),
     "hd_tile_metrics": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "hd_train_create": (C.c_int, [_P, C.c_int, _P, C.c_int, C.c_int]),

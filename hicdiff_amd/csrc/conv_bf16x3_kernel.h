@@ -136,7 +136,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
     constexpr int KS = CK / 16;                        // k16 MFMA steps per tap
     constexpr int IPP = CK / 8;                        // 8-channel items per staged pixel
     constexpr int SLAB16 = BN * 64;                    // bytes of one k16-slab (global: contiguous; LDS: one ring slot)
-    constexpr bool GL = NTAPS == 9 && HD_CONV_GLDS;   // weights by LDS-DMA
+    constexpr bool GL = conv_glds(WM, WN, CK, MODE, NTAPS);   // weights by LDS-DMA (per variant: conv_device.h)
     constexpr int GD = KS == 1 ? 2 : HD_GLDS_D;        // LDS-DMA: slabs requested ahead (16-channel slices: taps of 12 MFMAs are too short to cover one DMA's latency)
     constexpr int RING = (GL ? GD + 1 : 2) * KS;            // ring slots: the slabs (taps) being read, landing and -- with LDS-DMA -- in flight
     constexpr int NWH = SLAB16 / 16 / NT;              // 16-byte pieces per thread per k16-slab

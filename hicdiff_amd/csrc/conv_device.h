@@ -9,6 +9,16 @@
                           // ds_write_b128 into two (the round-2 path; A/B builds: make TAG=_g0 EXTRA=-DHD_CONV_GLDS=0).  The host's LDS plan follows it.
 #endif
 
+// ... per kernel variant (round 4).  profiles/r03_d measured the register path ahead on exactly two variants of the 256 x 64 tile at 64 x 64
+// maps -- plain loader with 16-channel slices (214 vs 222-224 us on 64 -> 64) and the GroupNorm-apply loader with 32-channel slices (262 vs
+// 278-299 us) -- and level or behind everywhere else.  Those two take the register path; HD_CONV_GLDS=2 forces LDS-DMA on every variant (A/B).
+// mode: the kernel's MODE template argument (IN_* ; IN_AFFINE_SILU_E = 3 keeps LDS-DMA: not measured apart).
+constexpr bool conv_glds(int wm, int wn, int ck, int mode, int ntaps) {
+    if (ntaps != 9 || HD_CONV_GLDS == 0) return false;
+    if (HD_CONV_GLDS == 1 && wm == 4 && wn == 1 && ((ck == 16 && mode == 0 /* IN_NONE */) || (ck == 32 && mode == 1 /* IN_AFFINE_SILU */))) return false;
+    return true;
+}
+
 #ifndef HD_GLDS_D
 #define HD_GLDS_D 1       // LDS-DMA path: slabs requested ahead of the one being read (ring = HD_GLDS_D + 1 slabs); 1 and 2 measure the same (profiles/r03_*), 1 needs a third less LDS
 #endif

@@ -99,12 +99,15 @@ static TileGeom pick_geom(int B, int H, int W, int BM, int KH, int KW, int strid
     for (int tw = 1; tw <= W && tw <= BM; ++tw) {
         for (int th = 1; th <= H && th * tw <= BM; ++th) {
             int tb = 1;
-            if (th == H && tw == W && !one_sample) { tb = BM / (H * W); if (tb > B) tb = B; if (tb > 32) tb = 32; if (tb < 1) tb = 1; }   // 32: loader-parameter table of the bf16x3 kernel
+            // (never clamped to B: a lone tile must take the geometry -- and with it the GroupNorm summation path -- it has inside a batch;
+            //  the last tile of any batch may be partly empty anyway)
+            if (th == H && tw == W && !one_sample) { tb = BM / (H * W); if (tb > 32) tb = 32; if (tb < 1) tb = 1; }   // 32: loader-parameter table of the bf16x3 kernel
             long lh = (long)(th - 1) * stride + KH, lw = (long)(tw - 1) * stride + KW;
             long npx = tb * lh * lw;
             if (npx > max_px) continue;
-            long tiles = (long)((B + tb - 1) / tb) * ((H + th - 1) / th) * ((W + tw - 1) / tw);
-            double eff = (double)B * H * W / ((double)tiles * BM);
+            // scored on one group of tb samples: the batch size cancels (tb == 1) or must not matter (whole images per tile)
+            long tiles = (long)((H + th - 1) / th) * ((W + tw - 1) / tw);
+            double eff = (double)tb * H * W / ((double)tiles * BM);
             double halo = (double)npx / (double)(tb * th * tw * stride * stride);
             double score = eff - 0.02 * halo;
             // ties go to the WIDER tile (tw ascends): a 16-pixel-wide window row keeps the LDS reads conflict-free (decode_row)
@@ -152,7 +155,9 @@ static ConvPlan plan_conv(const ConvArgs& a) {
     if (pl.fast && wide && big && taps9 && a.H * a.W >= cfg3_min_hw) { pl.BM = 256; pl.WM = 4; pl.cfg = 3; nthreads = 512; }
     pl.pitch = pl.fast ? (pl.ck == 32 && taps9 && HD_MFMA16 ? (size_t)160 : (size_t)4 * pl.ck + 16) : (size_t)17 * 4;   // bf16x3: see the kernel header (16 x 16 tiles want 160)
     // bf16x3: ring of unpadded k16-slabs of BN x 64 bytes, two taps' worth, three for the 3x3 kernels' LDS-DMA path (conv_bf16x3_kernel.h)
-    const size_t wbytes = pl.fast ? (size_t)((taps9 && HD_CONV_GLDS) ? (pl.ck == 16 ? 3 : HD_GLDS_D + 1) : 2) * (pl.ck / 16) * pl.BN * 64 : (size_t)2 * 16 * pl.BN * 4;
+    const int kmode = a.in_mode == IN_AFFINE_SILU && a.inE ? 3 : a.in_mode;     // the kernel's MODE (conv_kernel_mode)
+    const bool glds = conv_glds(pl.cfg >= 2 ? 4 : 2, pl.cfg == 2 ? 1 : 2, pl.ck, kmode, taps9 ? 9 : 0);
+    const size_t wbytes = pl.fast ? (size_t)(glds ? (pl.ck == 16 ? 3 : HD_GLDS_D + 1) : 2) * (pl.ck / 16) * pl.BN * 64 : (size_t)2 * 16 * pl.BN * 4;
     const size_t budget = pl.cfg == 3 ? LDS_BUDGET_8W : LDS_BUDGET;
     // bf16x3: one sink row per window; the 8-wave variant double-buffers the window; loader-parameter table
     // [2][vectors][TB * CK / 4 + 1] float4 (its TB is not known before the geometry: reserve for the largest possible)

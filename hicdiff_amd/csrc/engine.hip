@@ -114,13 +114,29 @@ struct hd_ctx {
     int precision = HD_PREC_BF16X3;   // arithmetic of the wide convolutions (hd_set_precision)
     int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
     // hipGraph replay of the fused sampler steps (device-generated noise only): one graph per
-    // (kind, B, S, tensor addresses); the step's scalars are written to `sp_dev` by a 1-thread kernel.
+    // (kind, B, S, tensor addresses); the step's scalars are written to the lane's `sp_dev` by a 1-thread kernel.
+    // A LANE is a stream of the context with its own graph cache and step-parameter block.  Lane 0 replays whole-batch steps out of
+    // `pool`.  Large steps (lanes_for) are cut into two half batches, one per lane, each with a workspace of its own: tiles are
+    // independent, so the halves may run side by side -- inside an hd_chain_begin / hd_chain_end bracket they are only
+    // ordered against the caller's stream at the two ends and drift apart, which lets one half's HBM-bound launches (1x1, attention,
+    // element-wise) run under the other half's MFMA-bound 3x3 convolutions.
     struct StepGraph { int kind, B, S, precision; const void *x, *aux, *x0; int seen; hipGraphExec_t exec; };
-    std::vector<StepGraph> graphs;
-    hipStream_t gstream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
-    StepParams* sp_dev = nullptr;
+    struct Lane {
+        hipStream_t st = nullptr;
+        hipEvent_t ev_out = nullptr;
+        StepParams* sp_dev = nullptr;
+        std::vector<StepGraph> graphs;
+        Pool pool;                 // half-batch workspace (lanes_for(B, S) == 2 only)
+        bool dirty = false;        // holds work the caller's stream has not been ordered after yet (chain bracket)
+        void drop_graphs() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); }
+    };
+    Lane lane[2];
+    hipEvent_t ev_in = nullptr;
     int use_graphs = -1;           // 1 / 0: always / never replay the fused steps from a hipGraph; -1 (default): by the amount of work, see run_step
+    int chains = -1;               // 2 / 1: always / never cut a replayed step into two half-batch lanes; -1 (default): by the amount of work, see lanes_for
+    int lane_delay_us = 0;         // experiment knob (HICDIFF_LANE_DELAY_US): lane 1 starts a chain this much later than lane 0
+    bool in_chain = false;         // between hd_chain_begin and hd_chain_end
+    bool forked = false;           // in_chain: the lanes already wait behind the caller's stream
     // test-only capture of intermediates (hicdiff_hip_debug.h)
     bool capture = false;
     std::unordered_map<std::string, Act> captured;
@@ -450,6 +466,11 @@ static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, 
     b.in_mode = IN_AFFINE_SILU; b.inA = A1; b.inB = B1; b.inE = E1; b.in_bstride = C;
     float *A2, *B2, *E2;
     HD_TRY(conv_gn(r, b, C, w.g2, w.b2, 0, 0, &A2, &B2, &E2));
+    if (r.c->capture && !r.dry) {      // test-only: the block's internals (per-sample affines as (B, 1, 1, C) maps)
+        auto vec = [&](float* p) { Act v{}; v.B = r.B; v.H = 1; v.W = 1; v.C = C; v.p = p; return v; };
+        HD_TRY(probe(r, w.name + ".h1", h1)); HD_TRY(probe(r, w.name + ".A1", vec(A1))); HD_TRY(probe(r, w.name + ".B1", vec(B1)));
+        HD_TRY(probe(r, w.name + ".h2", h2)); HD_TRY(probe(r, w.name + ".A2", vec(A2))); HD_TRY(probe(r, w.name + ".B2", vec(B2)));
+    }
     r.free(h1); r.free(A1); r.free(B1); r.free(E1);
     HD_TRY(r.act(H, W, C, out));
     if (w.has_res) {
@@ -469,6 +490,7 @@ static int unet_resblock(Run& r, const ResW& w, const Act& in0, const Act* in1, 
         if (rc == 1 && stats_done) *stats_done = true;
     }
     r.free(h2); r.free(A2); r.free(B2);
+    if (r.c->capture && !r.dry) HD_TRY(probe(r, w.name + ".out", *out));
     return 0;
 }
 
@@ -483,15 +505,18 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
     const bool fused = w.linear && w.fused && r.c->precision == HD_PREC_BF16X3;
     // chained q side (linattn_q_fused.hip): 64-channel maps of >= 256 pixels -- q, the attention output and the
     // pre-LayerNorm tensor never exist; the kernel reads x and the statistics and writes the block's output
-    const bool qchain = fused && C == 64 && HW >= 256 && w.wq && w.out.CoutPad == 64 && !r.dry;
-    // the dry run sizes the workspace for either arithmetic mode (hd_set_precision may switch later)
+    const bool qchain = fused && C == 64 && HW >= 256 && w.wq && w.out.CoutPad == 64;
+    // (the dry run takes exactly the allocations of the real one -- same sizes, same order -- for the arithmetic mode and time-row form it is
+    // given; dry_bytes sizes the workspace over every combination: a first-fit pool only replays a plan it was sized with)
     Act qkv{};
     if (!qchain) {
-        HD_TRY(r.act(H, W, (fused && !r.dry) ? 128 : 384, &qkv));
+        HD_TRY(r.act(H, W, fused ? 128 : 384, &qkv));
         ConvArgs q;
         q.in0 = x.p; q.C0 = C; q.B = r.B; q.H = H; q.W = W; q.IH = H; q.IW = W; q.stride = 1; q.pad = 0; q.cw = fused ? w.qonly : w.qkv; q.out = qkv.p;
         q.in_mode = IN_LAYERNORM; q.ln_stats = stats; q.ln_g = w.norm_g;
+        if (r.c->capture) { Act sa{}; sa.B = r.B; sa.H = H; sa.W = W; sa.C = 2; sa.p = stats; HD_TRY(probe(r, w.name + ".ln_stats", sa)); }
         HD_TRY(run_conv(r, q));
+        HD_TRY(probe(r, w.name + ".q", qkv));
         r.free(stats); stats = nullptr;
     }
     // q side, fused form (split-bf16 arithmetic, feature maps of >= 256 pixels so a conv tile never mixes samples):
@@ -500,7 +525,7 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
     const bool qfuse = fused && HW >= 256 && w.out.ck == 32;
     const bool lnfuse = qfuse && (C == 64 || C == 128);
     Act att{};
-    if ((!qfuse && !qchain) || r.dry) HD_TRY(r.act(H, W, 128, &att));
+    if (!qfuse && !qchain) HD_TRY(r.act(H, W, 128, &att));
     unsigned short* wfold = nullptr;
     const size_t wfold_bytes = (size_t)heads * w.out.CoutPad * 64 * sizeof(unsigned short);   // per sample
     if (fused) {
@@ -509,13 +534,14 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
         float *ctx, *scr;
         HD_TRY(r.alloc((size_t)r.B * heads * 32 * 32, &ctx));
         HD_TRY(r.alloc(std::max(slots * (32 + 32 + 32 * 32), linattn_scratch_floats(r.B, HW, heads)), &scr));
-        if (qfuse || qchain || r.dry) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
+        if (qfuse || qchain) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
         if (!r.dry) {
             float* pmax = scr; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
             HD_TRY(launch_linattn_kv_fused(x.p, w.wkv, r.B, HW, C, pmax, psum, pctx, r.st));
             HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nsplit, HW, ctx, r.st));
+            if (r.c->capture) { Act ca{}; ca.B = r.B; ca.H = heads; ca.W = 32; ca.C = 32; ca.p = ctx; HD_TRY(probe(r, w.name + ".ctx", ca)); }
             if (qfuse || qchain) HD_TRY(launch_linattn_fold_out(w.out.w, ctx, r.B, w.out.CoutPad, wfold, r.st, qchain ? 1 : 0));
-            else HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st));
+            else { HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st)); HD_TRY(probe(r, w.name + ".att", att)); }
         }
         r.free(ctx); r.free(scr);
     } else if (w.linear) {
@@ -531,7 +557,7 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
     }
     if (qchain) {
         HD_TRY(r.act(H, W, C, out));
-        HD_TRY(launch_linattn_q_fused(x.p, stats, w.wq, wfold, w.out.bias, w.out_g, out->p, r.B, HW, C, r.st));
+        if (!r.dry) HD_TRY(launch_linattn_q_fused(x.p, stats, w.wq, wfold, w.out.bias, w.out_g, out->p, r.B, HW, C, r.st));
         r.free(stats);
         if (wfold) r.free((float*)wfold);
         if (att.p) r.free(att);
@@ -541,18 +567,19 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
     HD_TRY(r.act(H, W, C, out));
     ConvArgs o;
     o.in0 = att.p; o.C0 = 128; o.B = r.B; o.H = H; o.W = W; o.IH = H; o.IW = W; o.stride = 1; o.pad = 0; o.cw = w.out;
-    if (qfuse && !r.dry) {
+    if (qfuse) {
         o.in0 = qkv.p; o.in_mode = IN_SOFTMAX32; o.cw.wsplit = wfold; o.w_bstride = wfold_bytes;
     }
     if (w.linear) {
         Act y{};
-        if (!lnfuse || r.dry) HD_TRY(r.act(H, W, C, &y));
-        if (lnfuse && !r.dry) {
+        if (!lnfuse) HD_TRY(r.act(H, W, C, &y));
+        if (lnfuse) {
             o.out = out->p; o.ep = EP_LN_RES; o.ep_ln_g = w.out_g; o.res = x.p;
             HD_TRY(run_conv(r, o));
         } else {
             o.out = y.p;
             HD_TRY(run_conv(r, o));
+            HD_TRY(probe(r, w.name + ".y", y));
             if (!r.dry) HD_TRY(launch_ln_residual(y.p, w.out_g, x.p, out->p, P, C, r.st));
         }
         if (y.p) r.free(y);
@@ -592,7 +619,7 @@ static int unet_forward(Run& r, const float* x, const float* cond, float* eps) {
     hd_ctx* c = r.c;
     const int S = r.S, n = c->arch.n_mults;
     Act h0; HD_TRY(r.act(S, S, c->arch.dim, &h0));
-    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, h0.p, r.B, S, 7, c->cin0, c->arch.dim, r.st));
+    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, h0.p, r.B, S, 7, c->cin0, c->arch.dim, r.st, c->precision == HD_PREC_BF16X3));
     HD_TRY(probe(r, "init_conv", h0));
     std::vector<Act> skips;
     Act cur = h0;
@@ -663,7 +690,7 @@ static int hicedrn_forward(Run& r, const float* x, const float* cond, float* eps
     const int S = r.S, F = c->arch.dim;
     const bool sr3 = c->arch.sr3;
     Act head; HD_TRY(r.act(S, S, F, &head));
-    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, head.p, r.B, S, 3, c->cin0, F, r.st));
+    if (!r.dry) HD_TRY(launch_conv_small_cin(x, cond, c->first_w, c->first_b, head.p, r.B, S, 3, c->cin0, F, r.st, c->precision == HD_PREC_BF16X3));
     HD_TRY(probe(r, "head", head));
     Act cur = head;
     for (size_t i = 0; i < c->body.size(); ++i) {
@@ -764,6 +791,8 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->ck = (a->dim % 32 == 0) ? 32 : 16;
     if (const char* k = getenv("HICDIFF_CK")) { if (atoi(k) == 16) c->ck = 16; }   // tuning experiments
     if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0 ? 1 : 0;
+    if (const char* g = getenv("HICDIFF_CHAINS")) c->chains = atoi(g) >= 2 ? 2 : 1;
+    if (const char* g = getenv("HICDIFF_LANE_DELAY_US")) c->lane_delay_us = std::max(0, std::min(atoi(g), 100000));
     if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
     else { c->first_ks = 3; c->first_cout = a->dim; c->film_n = a->number_resnet * (a->sr3 ? 1 : 2) * a->dim; }
@@ -777,11 +806,14 @@ void hd_destroy(hd_ctx* c) {
     for (void* p : c->owned) (void)hipFree(p);
     if (c->pool.base) (void)hipFree(c->pool.base);
     if (c->eps_buf) (void)hipFree(c->eps_buf);
-    for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (c->sp_dev) (void)hipFree(c->sp_dev);
+    for (auto& L : c->lane) {
+        L.drop_graphs();
+        if (L.pool.base) (void)hipFree(L.pool.base);
+        if (L.sp_dev) (void)hipFree(L.sp_dev);
+        if (L.ev_out) (void)hipEventDestroy(L.ev_out);
+        if (L.st) (void)hipStreamDestroy(L.st);
+    }
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
-    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
-    if (c->gstream) (void)hipStreamDestroy(c->gstream);
     delete c;
 }
 
@@ -791,42 +823,88 @@ int hd_load_weights(hd_ctx* c, const hd_named_tensor* tensors, int n, void* stre
     for (int i = 0; i < n; ++i) L.map[tensors[i].name] = &tensors[i];
     int rc = c->arch.kind == HD_ARCH_UNET ? load_unet(L) : load_hicedrn(L);
     if (rc == 0) c->loaded = true;
+    // the allocation plan follows what was loaded (which attention blocks have fused weight images): a workspace reserved before the
+    // first load is re-sized for the plan as it is now (grow-only; a no-op in the usual order, load then reserve)
+    if (rc == 0 && c->resB > 0 && !c->in_chain) rc = hd_reserve(c, c->resB, c->resS);
     return keep_err(c, rc);
 }
 
-int hd_workspace_bytes(const hd_ctx* cc, int B, int S, size_t* out) {
-    hd_ctx* c = const_cast<hd_ctx*>(cc);
-    if (!c || !out) return HD_EINVAL;
-    Pool saved = c->pool;
-    int rc = forward(c, nullptr, nullptr, HD_T_FLOAT32, 0.f, false, nullptr, nullptr, B, S, nullptr, true);
-    size_t high = c->pool.high;
-    c->pool = saved;
+// How a replayed step of B tiles of S x S is cut: two half-batch lanes from 512 k pixels per step on (measured: profiles/r04_a_*), one
+// whole-batch lane below.  A rule by the amount of work only; the halves are even so that kernels that pair images keep their pairs.
+static int lanes_for(const hd_ctx* c, int B, int S) {
+    if (B < 4) return 1;
+    if (c->chains >= 0) return c->chains >= 2 ? 2 : 1;
+    return (long long)B * S * S >= 524288 ? 2 : 1;
+}
+static int lane_first(int B) { return (B / 2 + 1) & ~1; }      // tiles of lane 0; lane 1 takes the rest
+
+static int dry_bytes(hd_ctx* c, int B, int S, size_t* out) {
+    // A first-fit pool replays a plan only if it was sized with that plan: the allocations differ between the two arithmetic modes
+    // (hd_set_precision may switch later) and between one time row (the sampler steps) and one per tile (hd_eps_forward).
+    const int saved = c->precision;
+    size_t high = 0;
+    int rc = 0;
+    for (int prec : {HD_PREC_BF16X3, HD_PREC_F32}) {
+        for (bool uniform : {false, true}) {
+            Pool scratch;
+            c->precision = prec;
+            rc = forward(c, nullptr, nullptr, HD_T_FLOAT32, 0.f, uniform, nullptr, nullptr, B, S, nullptr, true, nullptr, &scratch);
+            if (rc != 0) break;
+            high = std::max(high, scratch.high);
+        }
+        if (rc != 0) break;
+    }
+    c->precision = saved;
     if (rc != 0) return keep_err(c, rc);
     *out = high;
     return HD_OK;
 }
 
+int hd_workspace_bytes(const hd_ctx* cc, int B, int S, size_t* out) {
+    hd_ctx* c = const_cast<hd_ctx*>(cc);
+    if (!c || !out) return HD_EINVAL;
+    return dry_bytes(c, B, S, out);
+}
+
+static int grow_block(hd_ctx* c, Pool& pool, size_t need, bool* synced) {
+    if (need <= pool.cap) return HD_OK;
+    if (!*synced) {
+        if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+        *synced = true;
+        for (auto& L : c->lane) L.drop_graphs();     // captured addresses die with the old block
+    }
+    if (pool.base) (void)hipFree(pool.base);
+    pool.base = nullptr; pool.cap = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(workspace) failed");
+    pool.base = (char*)p; pool.cap = need;
+    return HD_OK;
+}
+
 int hd_reserve(hd_ctx* c, int B, int S) {
     if (!c) return HD_EINVAL;
+    if (c->in_chain) return fail(c, HD_ESTATE, "hd_reserve inside an hd_chain_begin / hd_chain_end bracket");
     size_t need = 0;
-    HD_TRY(hd_workspace_bytes(c, B, S, &need));
+    HD_TRY(dry_bytes(c, B, S, &need));
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
-    if (need > c->pool.cap) {
-        if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
-        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        c->graphs.clear();                       // captured addresses die with the old block
-        if (c->pool.base) (void)hipFree(c->pool.base);
-        c->pool.base = nullptr; c->pool.cap = 0;
-        void* p = nullptr;
-        if (hipMalloc(&p, need) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(workspace) failed");
-        c->pool.base = (char*)p; c->pool.cap = need;
+    bool synced = false;
+    HD_TRY(grow_block(c, c->pool, need, &synced));
+    if (lanes_for(c, B, S) == 2) {
+        const int b0 = lane_first(B);
+        size_t n0 = 0, n1 = 0;
+        HD_TRY(dry_bytes(c, b0, S, &n0));
+        HD_TRY(dry_bytes(c, B - b0, S, &n1));
+        HD_TRY(grow_block(c, c->lane[0].pool, n0, &synced));
+        HD_TRY(grow_block(c, c->lane[1].pool, n1, &synced));
     }
     const size_t en = (size_t)B * S * S;
     if (en > c->eps_cap) {
-        if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
-        for (auto& g : c->graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        c->graphs.clear();
+        if (!synced) {
+            if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+            for (auto& L : c->lane) L.drop_graphs();
+        }
         if (c->eps_buf) (void)hipFree(c->eps_buf);
+        c->eps_buf = nullptr; c->eps_cap = 0;
         void* p = nullptr;
         if (hipMalloc(&p, en * sizeof(float)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(eps) failed");
         c->eps_buf = (float*)p; c->eps_cap = en;
@@ -842,13 +920,70 @@ int hd_eps_forward(hd_ctx* c, const float* x, const void* t, int t_kind, const f
 
 // One fused sampler step: eps-net + update.  kind 0: ancestral (aux = cond), 1: DDRM (aux = y).
 static int step_body(hd_ctx* c, int kind, float* x, const float* aux, const float* noise, const StepParams& v, float* x0_out,
-                     int B, int S, hipStream_t st, const StepParams* sp) {
+                     int B, int S, hipStream_t st, const StepParams* sp, Pool* pool = nullptr, float* eps = nullptr) {
     const float* cond = kind == 0 ? aux : nullptr;
-    HD_TRY(forward(c, x, nullptr, HD_T_FLOAT32, v.f[0], true, cond, c->eps_buf, B, S, st, false, sp));
+    if (!eps) eps = c->eps_buf;
+    HD_TRY(forward(c, x, nullptr, HD_T_FLOAT32, v.f[0], true, cond, eps, B, S, st, false, sp, pool));
     if (kind == 0)
-        return launch_ddpm_update(x, c->eps_buf, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], x0_out, B, S, v.seed, v.tile_off, v.step, sp, st, v.f[6]);
-    return launch_ddrm_update(x, c->eps_buf, aux, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], v.f[6], v.f[7], v.f[8], x0_out, B, S, v.seed,
+        return launch_ddpm_update(x, eps, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], x0_out, B, S, v.seed, v.tile_off, v.step, sp, st, v.f[6]);
+    return launch_ddrm_update(x, eps, aux, noise, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], v.f[6], v.f[7], v.f[8], x0_out, B, S, v.seed,
                               v.tile_off, v.step, sp, st);
+}
+
+static int lanes_setup(hd_ctx* c) {
+    if (c->ev_in) return HD_OK;
+    for (auto& L : c->lane) {
+        if (hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&L.ev_out, hipEventDisableTiming) != hipSuccess ||
+            hipMalloc((void**)&L.sp_dev, sizeof(StepParams)) != hipSuccess)
+            return fail(c, HD_EHIP, "graph stream setup failed");
+    }
+    if (hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess) { c->ev_in = nullptr; return fail(c, HD_EHIP, "graph stream setup failed"); }
+    return HD_OK;
+}
+
+// Order the caller's stream after everything the lanes hold (the end of a chain bracket, or a step inside one that has to run on the
+// caller's stream); the next replayed step forks again.
+static int lanes_join(hd_ctx* c, hipStream_t user) {
+    for (auto& L : c->lane) {
+        if (!L.dirty) continue;
+        if (hipEventRecord(L.ev_out, L.st) != hipSuccess || hipStreamWaitEvent(user, L.ev_out, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+        L.dirty = false;
+    }
+    c->forked = false;
+    return HD_OK;
+}
+
+// One lane's share of a replayed step: its scalars, then the eager first call / the capture / the replay, all on the lane's stream.
+static int lane_step(hd_ctx* c, hd_ctx::Lane& L, Pool* pool, int kind, float* x, const float* aux, const StepParams& v, float* x0_out, float* eps,
+                     int B, int S) {
+    hd_ctx::StepGraph* g = nullptr;
+    for (auto& e : L.graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == c->precision && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
+    if (!g) {
+        if (L.graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
+            if (L.graphs.front().exec) (void)hipGraphExecDestroy(L.graphs.front().exec);
+            L.graphs.erase(L.graphs.begin());
+        }
+        L.graphs.push_back({kind, B, S, c->precision, x, aux, x0_out, 0, nullptr});
+        g = &L.graphs.back();
+    }
+    HD_TRY(launch_set_step_params(L.sp_dev, v, L.st));
+    L.dirty = true;
+    if (g->seen < 1) {                    // first call: eager (sets function attributes, warms caches)
+        g->seen++;
+        return step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, L.st, L.sp_dev, pool, eps);
+    }
+    if (!g->exec) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(L.st, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail(c, HD_EHIP, "hipStreamBeginCapture failed");
+        const int rc = step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, L.st, L.sp_dev, pool, eps);
+        hipError_t e1 = hipStreamEndCapture(L.st, &graph);
+        if (rc != 0 || e1 != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc ? rc : fail(c, HD_EHIP, "hipStreamEndCapture failed"); }
+        hipError_t e2 = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e2 != hipSuccess) { g->exec = nullptr; return fail(c, HD_EHIP, "hipGraphInstantiate failed"); }
+    }
+    if (hipGraphLaunch(g->exec, L.st) != hipSuccess) return fail(c, HD_EHIP, "hipGraphLaunch failed");
+    return HD_OK;
 }
 
 static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float* noise, const StepParams& v, float* x0_out, int B,
@@ -859,43 +994,36 @@ static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float
     // the replay (unet40: 4 tiles 2.23 vs 2.46 ms per step, 64 tiles 2.89 vs 3.08; profiles/r03_f_*), at full batches the two measure the same
     // (unet64, 256 tiles: 13.0-13.2 ms either way) and the replay keeps the step independent of what the host thread is doing.
     const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= 262144;
-    if (!graphs || noise != nullptr || hd_prof_is_on() || c->capture) return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
-    if (!c->gstream) {
-        if (hipStreamCreateWithFlags(&c->gstream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&c->sp_dev, sizeof(StepParams)) != hipSuccess)
-            return fail(c, HD_EHIP, "graph stream setup failed");
+    if (!graphs || noise != nullptr || hd_prof_is_on() || c->capture) {
+        if (c->in_chain) HD_TRY(lanes_join(c, user));
+        return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
     }
-    hd_ctx::StepGraph* g = nullptr;
-    for (auto& e : c->graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == c->precision && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
-    if (!g) {
-        if (c->graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
-            if (c->graphs.front().exec) (void)hipGraphExecDestroy(c->graphs.front().exec);
-            c->graphs.erase(c->graphs.begin());
+    HD_TRY(lanes_setup(c));
+    int nl = lanes_for(c, B, S);
+    const int b0 = nl == 2 ? lane_first(B) : B;
+    if (nl == 2 && (c->lane[0].pool.cap == 0 || c->lane[1].pool.cap == 0)) nl = 1;    // reserved before hd_set_chains(2): whole-batch lane
+    // order after the caller's stream (every step; inside a chain bracket only at its first replayed step), run on the lanes, hand back
+    if (!c->in_chain || !c->forked) {
+        if (hipEventRecord(c->ev_in, user) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+        for (auto& L : c->lane) if (hipStreamWaitEvent(L.st, c->ev_in, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+        if (c->in_chain) {
+            c->forked = true;
+            if (nl == 2 && c->lane_delay_us > 0) HD_TRY(launch_spin_us(c->lane_delay_us, c->lane[1].st));
         }
-        c->graphs.push_back({kind, B, S, c->precision, x, aux, x0_out, 0, nullptr});
-        g = &c->graphs.back();
     }
-    // order after the caller's stream, run on the engine's capturable stream, hand back
-    if (hipEventRecord(c->ev_in, user) != hipSuccess || hipStreamWaitEvent(c->gstream, c->ev_in, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
-    HD_TRY(launch_set_step_params(c->sp_dev, v, c->gstream));
-    int rc = 0;
-    if (g->seen < 1) {                    // first call: eager (sets function attributes, warms caches)
-        rc = step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, c->gstream, c->sp_dev);
-        g->seen++;
+    int rc;
+    if (nl == 1) {
+        rc = lane_step(c, c->lane[0], &c->pool, kind, x, aux, v, x0_out, c->eps_buf, B, S);
     } else {
-        if (!g->exec) {
-            hipGraph_t graph = nullptr;
-            if (hipStreamBeginCapture(c->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) return fail(c, HD_EHIP, "hipStreamBeginCapture failed");
-            rc = step_body(c, kind, x, aux, nullptr, v, x0_out, B, S, c->gstream, c->sp_dev);
-            hipError_t e1 = hipStreamEndCapture(c->gstream, &graph);
-            if (rc != 0 || e1 != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); return rc ? rc : fail(c, HD_EHIP, "hipStreamEndCapture failed"); }
-            hipError_t e2 = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e2 != hipSuccess) { g->exec = nullptr; return fail(c, HD_EHIP, "hipGraphInstantiate failed"); }
-        }
-        if (hipGraphLaunch(g->exec, c->gstream) != hipSuccess) return fail(c, HD_EHIP, "hipGraphLaunch failed");
+        const size_t off = (size_t)b0 * S * S;
+        StepParams v1 = v;
+        v1.tile_off += (uint64_t)b0;
+        rc = lane_step(c, c->lane[0], &c->lane[0].pool, kind, x, aux, v, x0_out, c->eps_buf, b0, S);
+        if (rc == 0)
+            rc = lane_step(c, c->lane[1], &c->lane[1].pool, kind, x + off, aux ? aux + off : nullptr, v1, x0_out ? x0_out + off : nullptr,
+                           c->eps_buf + off, B - b0, S);
     }
-    if (hipEventRecord(c->ev_out, c->gstream) != hipSuccess || hipStreamWaitEvent(user, c->ev_out, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
+    if (!c->in_chain || rc != 0) { const int rj = lanes_join(c, user); if (rc == 0) rc = rj; }
     return rc;
 }
 
@@ -930,6 +1058,35 @@ int hd_set_graphs(hd_ctx* c, int enable) {
     if (!c) return HD_EINVAL;
     c->use_graphs = enable != 0 ? 1 : 0;
     return HD_OK;
+}
+
+int hd_set_chains(hd_ctx* c, int n) {
+    if (!c || n < 0 || n > 2) return HD_EINVAL;
+    if (c->in_chain) return fail(c, HD_ESTATE, "hd_set_chains inside an hd_chain_begin / hd_chain_end bracket");
+    c->chains = n == 0 ? -1 : n;
+    if (c->resB > 0 && hd_reserve(c, c->resB, c->resS) != HD_OK) return HD_EHIP;      // the half-batch workspaces, if they are now needed
+    return HD_OK;
+}
+
+int hd_chains_for(const hd_ctx* c, int B, int S) {
+    if (!c || B < 1 || S < 1) return HD_EINVAL;
+    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= 262144;
+    return graphs ? lanes_for(c, B, S) : 1;
+}
+
+int hd_chain_begin(hd_ctx* c, void* stream) {
+    if (!c) return HD_EINVAL;
+    if (c->in_chain) return fail(c, HD_ESTATE, "hd_chain_begin: a bracket is already open on this context");
+    (void)stream;
+    c->in_chain = true; c->forked = false;
+    return HD_OK;
+}
+
+int hd_chain_end(hd_ctx* c, void* stream) {
+    if (!c) return HD_EINVAL;
+    if (!c->in_chain) return fail(c, HD_ESTATE, "hd_chain_end without hd_chain_begin");
+    c->in_chain = false;
+    return keep_err(c, lanes_join(c, (hipStream_t)stream));
 }
 
 int hd_q_sample(hd_ctx* c, const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S, void* stream) {

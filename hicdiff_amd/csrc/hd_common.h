@@ -124,7 +124,7 @@ bool conv_winograd_enabled();                 // the switch as it stands now (hd
 int launch_transpose(const float* src, float* dst, int rows, int cols, int dst_ld, int dst_col0, hipStream_t st);
 
 int launch_conv_small_cin(const float* x, const float* cond, const float* w, const float* bias, float* out,
-                          int B, int S, int KS, int Cin, int Cout, hipStream_t st);
+                          int B, int S, int KS, int Cin, int Cout, hipStream_t st, bool lanes_ok = false);   // lanes_ok: see small_kernels.hip
 int launch_rowdot(const float* x, const float* w, const float* bias, float* out, size_t P, int C, hipStream_t st);
 
 int launch_time_mlp(const void* t, int t_kind, float tval, const StepParams* sp, int sr3, int Bt, int dim, int time_dim, const float* w1t,
@@ -187,6 +187,7 @@ int launch_ddrm_update(float* x, const float* eps, const float* y, const float* 
                        float* x0_out, int B, int S, uint64_t seed, uint64_t tile_off, uint32_t step, const StepParams* sp,
                        hipStream_t st, uint32_t tile_add = 0);
 int launch_set_step_params(StepParams* dst, const StepParams& v, hipStream_t st);
+int launch_spin_us(int us, hipStream_t st);
 int launch_q_sample(const float* x0, const float* noise, const float* a, const float* s, float* out, int B, int S,
                     hipStream_t st);
 int launch_loss(const float* pred, const float* target, int l2, float* out, int B, int S, hipStream_t st);

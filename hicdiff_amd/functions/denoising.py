@@ -4,6 +4,8 @@ each step is ONE ``hd_ddrm_step`` call (epsilon-network + three-case update fuse
 (``hd_ddrm_general_update``) and ``V`` of the result."""
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from .. import _lib as L
@@ -45,25 +47,28 @@ def efficient_generalized_steps(x, seq, model, b, H_funcs, y_0, sigma_0, etaB, e
         seq_next = [-1] + seq[:-1]
         xs, x0_preds = [xt.clone()], []
         x0 = torch.empty_like(xt)
-        for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
-            at, at_next = ab[i + 1], ab[j + 1]
-            co = L.HdDdrmCoef()
-            co.sqrt_at, co.sqrt_1m_at, co.sqrt_at_next = float(at.sqrt()), float((1 - at).sqrt()), float(at_next.sqrt())
-            sigma_next = (1 - at_next).sqrt() / at_next.sqrt()
-            co.sigma_next, co.sigma_0, co.etaA, co.etaB, co.etaC = float(sigma_next), float(sigma_0), float(etaA), float(etaB), float(etaC)
-            co.time_value = float(i)
-            z = None
-            if noise is not None:
-                after = bool(sigma_next < sigma_0)
-                z = torch.empty((3, n, d), device=x.device, dtype=torch.float32)
-                z[0] = noise.randn((n, d))
-                za = noise.randn((n, d if after else 0))
-                if after:
-                    z[1] = za
-                z[2] = noise.randn((n, d))
-            eng.ddrm_step(xt, y, z, co, x0, seed=seed, tile_offset=tile_offset, step=k)
-            if keep == "all":
-                xs.append(xt.clone()); x0_preds.append(x0.clone())
+        # a chain bracket (Engine.chain) when nothing has to see the state between steps on this stream: device noise, last state only
+        bracket = eng.chain(n, hh) if (noise is None and keep != "all") else contextlib.nullcontext()
+        with bracket:
+            for k, (i, j) in enumerate(zip(reversed(seq), reversed(seq_next))):
+                at, at_next = ab[i + 1], ab[j + 1]
+                co = L.HdDdrmCoef()
+                co.sqrt_at, co.sqrt_1m_at, co.sqrt_at_next = float(at.sqrt()), float((1 - at).sqrt()), float(at_next.sqrt())
+                sigma_next = (1 - at_next).sqrt() / at_next.sqrt()
+                co.sigma_next, co.sigma_0, co.etaA, co.etaB, co.etaC = float(sigma_next), float(sigma_0), float(etaA), float(etaB), float(etaC)
+                co.time_value = float(i)
+                z = None
+                if noise is not None:
+                    after = bool(sigma_next < sigma_0)
+                    z = torch.empty((3, n, d), device=x.device, dtype=torch.float32)
+                    z[0] = noise.randn((n, d))
+                    za = noise.randn((n, d if after else 0))
+                    if after:
+                        z[1] = za
+                    z[2] = noise.randn((n, d))
+                eng.ddrm_step(xt, y, z, co, x0, seed=seed, tile_offset=tile_offset, step=k)
+                if keep == "all":
+                    xs.append(xt.clone()); x0_preds.append(x0.clone())
         if keep != "all":
             xs, x0_preds = [xt], [x0]
     return xs, x0_preds

@@ -74,7 +74,9 @@ typedef struct {
 } hd_named_tensor;
 
 /* ABI revision of this header.  hd_abi_version() returns the revision the library was built from: a binding checks it once after
- * loading.  Revision 3 (round 3) put `struct_bytes` in front of the two per-step coefficient structs.
+ * loading.  Revision 3 (round 3) put `struct_bytes` in front of the two per-step coefficient structs.  Entry points
+ * added since (round 4: hd_chain_begin / hd_chain_end / hd_set_chains / hd_chains_for) leave the revision alone: nothing a revision-3 binding calls
+ * changed, and a binding that wants the new symbols fails at symbol lookup on an older library.
  *
  * Size-prefixed structs.  The caller stores sizeof(its own struct) in `struct_bytes`; the library copies that many bytes (never more)
  * into a zeroed struct of its own revision, so a caller built against an OLDER revision of a struct keeps working (the fields it does
@@ -169,6 +171,20 @@ int hd_fwht(float* data, int N, int L, float scale, void* stream);
  * (every kernel is then launched eagerly on the caller's stream), 1 forces it; untouched, a context replays steps of at least
  * 256 k pixels (B*S*S) and launches smaller ones eagerly (measured faster there); env HICDIFF_GRAPHS=0|1 forces either at hd_create. */
 int hd_set_graphs(hd_ctx* ctx, int enable);
+
+/* The loop of p_sample_loop (src/hicdiff.py:603-620; conditional src/hicdiff_condition.py:676-678; the DDRM loop
+ * src/functions/denoising.py:38-109) as a bracket around the per-step calls.  Between hd_chain_begin and hd_chain_end the replayed
+ * steps (hd_ddpm_step / hd_ddrm_step with device noise) are ordered against `stream` only at the first step and at hd_chain_end: the
+ * caller must not touch x / cond / y / x0_out on its stream inside the bracket.  A step that has to run on the caller's stream
+ * (replayed noise, a batch too small to replay) joins first, so mixing stays correct, only slower.  Large steps are cut into two
+ * half-batch chains (tiles are independent for the whole chain) that advance side by side on two streams of the
+ * context and only meet at hd_chain_end -- results are bit-identical to the single chain.  hd_set_chains: 2 always cuts, 1 never,
+ * 0 restores the default (from 512 k pixels per step on); env HICDIFF_CHAINS=1|2 sets it at hd_create.  hd_reserve / hd_set_chains
+ * inside a bracket return HD_ESTATE. */
+int hd_chain_begin(hd_ctx* ctx, void* stream);
+int hd_chain_end(hd_ctx* ctx, void* stream);
+int hd_set_chains(hd_ctx* ctx, int n);
+int hd_chains_for(const hd_ctx* ctx, int B, int S);   /* how many chains a replayed step of B tiles of S x S is cut into: 1 or 2 */
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 

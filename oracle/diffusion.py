@@ -162,6 +162,18 @@ class DiffusionRef:
                 kept[t] = img.clone()
         return (img, kept) if keep_every else img
 
+    def interpolate(self, x1, x2, noise: TorchNoise, t: Optional[int] = None, lam: float = 0.5):
+        """src/hicdiff.py:673-691: both tiles diffused to step t (two q_sample draws, x1 first), mixed, then p_sample for i = t-1 .. 0."""
+        t = self.T - 1 if t is None else t
+        tb = torch.full((x1.shape[0],), t, dtype=torch.long)
+        xt1 = self.q_sample(x1, tb, noise.randn(x1.shape))
+        xt2 = self.q_sample(x2, tb, noise.randn(x2.shape))
+        img = (1 - lam) * xt1 + lam * xt2
+        for i in reversed(range(0, t)):
+            z = noise.randn(img.shape) if i > 0 else None
+            img, _, _ = self.p_sample(img, i, None, z)
+        return img
+
     def ddim_sample(self, shape, noise: TorchNoise):
         """src/hicdiff.py:622-664."""
         T, S, eta = self.T, self.sampling_timesteps, self.eta

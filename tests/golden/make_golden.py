@@ -305,6 +305,24 @@ def case_trajectories():
     save("trajectories", **out)
 
 
+def case_interpolate():
+    """GaussianDiffusion.interpolate (src/hicdiff.py:673-691): two tiles diffused to step t, mixed with weight lam, denoised from t - 1."""
+    out = {}
+    T, B, S = 50, 2, 40
+    m, cfg = build_unet("uncond")
+    d = R0.GaussianDiffusion(m, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear")
+    oref = OD.DiffusionRef(oracle_model(m, cfg), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+    x1, x2 = tiles(301, B, S), tiles(302, B, S)
+    out["x1"], out["x2"] = x1, x2
+    for tag, t, lam, seed in (("default", None, 0.5, 611), ("t20_lam03", 20, 0.3, 612)):
+        torch.manual_seed(seed)
+        ref = d.interpolate(x1, x2, t=t, lam=lam)
+        mine = oref.interpolate(x1, x2, OD.TorchNoise(seed), t=t, lam=lam)
+        check(f"interpolate {tag}", ref, mine, tol=5e-4)
+        out[tag] = ref
+    save("interpolate", **out)
+
+
 def case_objectives():
     """objective = 'pred_x0' / 'pred_v' (src/hicdiff.py:441,461,566-580,733-741; no reference driver sets them): a 20-step ancestral chain
     and a loss value each, same network weights read as an x0- / v-predictor."""
@@ -698,6 +716,7 @@ CASES = {
     "trajectories": case_trajectories,
     "losses": case_losses,
     "objectives": case_objectives,
+    "interpolate": case_interpolate,
 }
 
 if __name__ == "__main__":

@@ -217,6 +217,25 @@ def test_large_grid_is_correct_and_bitwise_reproducible(mode, prec):
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+_BIG_REF = {}
+
+
+def test_large_grid_8wave_tile_256_to_256_at_64(prec):
+    """hicedrn's body layer at the grid `bench.py --workload hicedrn64` launches it on: 256 -> 256 channels at 64 x 64, 128 tiles ->
+    2 048 M tiles x 2 N tiles = 4 096 workgroups of the 8-wave 256 x 128 kernel, eight 32-channel K slices per tap.  Three sampled
+    tiles against torch CPU conv2d, the whole output bit for bit run to run, and a slice of the batch on its own bit for bit."""
+    B, S, Cc = 128, 64, 256
+    x = rnd(1, B, Cc, S, S)
+    w, b = rnd(2, Cc, Cc, 3, 3) / 48, rnd(3, Cc)
+    pick = [0, 77, 127]
+    if "ref" not in _BIG_REF:
+        _BIG_REF["ref"] = F.conv2d(x[pick], w, b, padding=1)
+    out = run_conv(x, None, w, b, 3, 0 | prec)
+    assert rel_err(_BIG_REF["ref"], out[pick]) < PRECS[prec]
+    assert torch.equal(out, run_conv(x, None, w, b, 3, 0 | prec))
+    assert torch.equal(out[40:44], run_conv(x[40:44], None, w, b, 3, 0 | prec))
+
+
 @pytest.mark.parametrize("B,S,Cc", [(2, 16, 64), (3, 16, 128), (2, 16, 256), (32, 64, 64), (48, 32, 128)])
 def test_linear_attention_q_side_fused(B, S, Cc):
     """softmax_d(q) -> context -> to_out -> LayerNorm -> + x as ONE convolution (context folded into the weight per

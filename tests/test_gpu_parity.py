@@ -272,6 +272,20 @@ def test_batch_independence_and_determinism_full_size():
     assert torch.equal(full, part)
 
 
+@pytest.mark.parametrize("dim,mults,S", [(32, (1, 2, 4), 40), (16, (1, 2, 4), 24), (64, (1, 2, 4, 8), 40)])
+def test_batch_independence_odd_shapes(dim, mults, S):
+    """Slices of a batch equal the batch bit for bit on maps whose pixel counts are not powers of two (100-, 36-, 25-pixel maps): the
+    property the tile sharding and the two half-batch chains rest on.  (Round 4: a kernel choice keyed on B*HW*C % 1024 broke it for the
+    first shape.)"""
+    m = product_unet("uncond", dim, mults)
+    B = 6
+    x = tiles(3, B, S).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(1)).cuda()
+    full = m(x, t)
+    for cut in (1, 2, 4):
+        assert torch.equal(full, torch.cat([m(x[:cut], t[:cut]), m(x[cut:], t[cut:])])), cut
+
+
 def test_device_noise_is_rank_count_invariant():
     """Philox noise is keyed by the GLOBAL tile index: sampling tiles [0,8) in one go equals sampling
     [0,3) and [3,8) with tile_offset -- the property the 8-GPU sharding relies on."""
@@ -396,3 +410,15 @@ def test_vision_metrics_object_api(tmp_path, precision):
     xs, _ = efficient_generalized_steps(x, range(0, 1000, 100), m, v.betas.cuda(), MakeFunc("deno", 1, 16, "cuda"), sp, 0.1, etaB=1.0, etaA=0.85,
                                         etaC=0.85, seed=99, tile_offset=0)
     assert torch.equal(torch.from_numpy(pred), xs[-1].cpu())
+
+
+@pytest.mark.parametrize("tag,t,lam,seed", [("default", None, 0.5, 611), ("t20_lam03", 20, 0.3, 612)])
+def test_interpolate_golden(tag, t, lam, seed):
+    """GaussianDiffusion.interpolate (src/hicdiff.py:673-691) against the reference's own output: two q_sample draws (x1 first), the mix,
+    then the fused step for i = t - 1 .. 0 with the reference's noise order replayed."""
+    from hicdiff_amd.hicdiff import HostReplayNoise
+    g = golden("interpolate")
+    d = diffusion_class("uncond")(product_unet("uncond"), image_size=40, timesteps=50, loss_type="l2", beta_schedule="linear").cuda()
+    d.noise_source = HostReplayNoise(seed, "cuda")
+    got = d.interpolate(g["x1"].cuda(), g["x2"].cuda(), t=t, lam=lam)
+    assert rel_err(g[tag], got) < CHAIN_TOL

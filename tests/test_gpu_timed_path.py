@@ -243,6 +243,131 @@ def test_precision_switch_drops_captured_graphs():
     assert rel_err(exact, fast) < CHAIN_TOL
 
 
+# ---------------------------------------------------------------- two half-batch chains on two streams (hd_chain_begin / hd_chain_end)
+
+def _eng(model):
+    return model.engine(torch.device("cuda", torch.cuda.current_device()))
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
+def test_two_half_batch_chains_equal_the_single_chain(kind, precision):
+    """A replayed chain cut into two half-batch chains that advance side by side on two streams of the context (engine.hip lanes) is the
+    single chain bit for bit: 6 tiles -> 4 + 2, noise keyed by the global tile, tile_offset != 0.  The single chain is the one the oracle
+    tests above pin."""
+    B, S, T, seed = 6, 40, 30, 515
+    net = product_unet(kind, 32, (1, 2, 4))
+    d = diffusion_class(kind)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed, d.tile_offset = seed, 3
+    eng = _eng(net)
+    lq = tiles(21, B, S).cuda()
+    run = (lambda: d.sample(torch.zeros(B, 1, S, S))) if kind == "uncond" else (lambda: d.super_resolution(lq))
+    eng.set_chains(1)
+    assert eng.chains_for(B, S) == 1
+    one = run()
+    eng.set_chains(2)
+    assert eng.chains_for(B, S) == 2
+    two = run()
+    assert torch.equal(one, two)
+    assert torch.equal(two, run())                      # and repeats
+    # the per-step form without a bracket (p_sample: fork and join around every step) goes through the same lanes
+    x = torch.randn(B, 1, S, S, generator=torch.Generator().manual_seed(1)).cuda()
+    cond = lq if kind != "uncond" else None
+    outs = []
+    for n in (1, 2):
+        eng.set_chains(n)
+        outs.append([d.p_sample(x, 7, cond), d.p_sample(x, 7, cond), d.p_sample(x, 7, cond)][-1])     # eager, capture, replay
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_two_half_batch_ddrm_chains_equal_the_single_chain(precision):
+    from hicdiff_amd.functions.H_func import MakeFunc
+    from hicdiff_amd.functions.denoising import efficient_generalized_steps
+    from oracle import ddrm as ODD
+    B, S, seed, sigma_0 = 6, 40, 77, 0.1
+    m = product_hicedrn("uncond", 2)
+    betas = ODD.ddrm_betas("linear", 1000).cuda()
+    y0 = (tiles(5, B, S) + sigma_0 * torch.randn((B, 1, S, S), generator=torch.Generator().manual_seed(6))).clamp(-1, 1).cuda()
+    x = device_randn(B, S, seed, 0, 1000)
+    H = MakeFunc("deno", 1, S, device="cuda")
+    eng = _eng(m)
+    outs = []
+    for n in (1, 2, 2):
+        eng.set_chains(n)
+        xs, x0s = efficient_generalized_steps(x.clone(), range(0, 1000, 50), m, betas, H, y0, sigma_0, etaB=1.0, etaA=0.85, etaC=0.85,
+                                              noise=None, seed=seed, keep="last")
+        outs.append((xs[-1].clone(), x0s[-1].clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[1][0], outs[2][0])
+
+
+def test_chain_bracket_mixes_with_steps_on_the_callers_stream():
+    """Inside a bracket a step that must run on the caller's stream (replayed noise) joins the lanes first and the next replayed step
+    forks again: the mixed sequence equals the same sequence issued step by step without a bracket."""
+    import contextlib
+    from hicdiff_amd import _lib as L
+    B, S = 6, 16
+    net = product_unet("uncond", 16, (1, 2))
+    eng = _eng(net)
+    eng.set_chains(2)
+    start = device_randn(B, S, 3, 0, 1)
+    z = device_randn(B, S, 4, 0, 2)
+    co = L.HdDdpmCoef()
+    co.sqrt_recip_alphas_cumprod, co.sqrt_recipm1_alphas_cumprod = 1.2, 0.66
+    co.posterior_mean_coef1, co.posterior_mean_coef2, co.sigma, co.time_value = 0.3, 0.69, 0.2, 400.0
+
+    def sequence(bracket):
+        x = start.clone()
+        ctx = eng.chain(B, S) if bracket else contextlib.nullcontext()
+        with ctx:
+            for k in range(8):
+                eng.ddpm_step(x, None, z if k in (3, 6) else None, co, None, seed=9, tile_offset=0, step=k + 1)
+        return x.clone()
+
+    plain = sequence(False)
+    assert torch.equal(sequence(True), plain)
+    assert torch.equal(sequence(True), plain)
+
+
+def test_chain_bracket_state_errors():
+    from hicdiff_amd import _lib as L
+    net = product_unet("uncond", 16, (1, 2))
+    eng = _eng(net)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert eng.lib.hd_chain_end(eng.ctx, st) == L.HD_ESTATE
+    assert eng.lib.hd_chain_begin(eng.ctx, st) == 0
+    assert eng.lib.hd_chain_begin(eng.ctx, st) == L.HD_ESTATE
+    assert eng.lib.hd_reserve(eng.ctx, 8, 16) == L.HD_ESTATE
+    assert eng.lib.hd_set_chains(eng.ctx, 2) == L.HD_ESTATE
+    assert b"bracket" in eng.lib.hd_last_error(eng.ctx)
+    assert eng.lib.hd_chain_end(eng.ctx, st) == 0
+    assert eng.lib.hd_set_chains(eng.ctx, 3) == L.HD_EINVAL
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond"])
+def test_two_chains_at_bench_batch_size_equal_the_single_chain(kind):
+    """bench.py's default workload as it now runs: 256 tiles of 64x64 as two 128-tile chains (the library's default rule from 512 k
+    pixels per step on), six steps inside a bracket, against the single 256-tile chain."""
+    B, S, T = 256, 64, 1000
+    net = product_unet(kind)
+    d = diffusion_class(kind)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    eng = _eng(net)
+    assert eng.chains_for(B, S) == 2                    # the default
+    cond = tiles(33, B, S).cuda() if kind == "cond" else None
+    start = device_randn(B, S, 1234, 0, T)
+
+    def six_steps():
+        x = start.clone()
+        with eng.chain(B, S):
+            for t in range(T - 1, T - 7, -1):
+                d._step_inplace(x, t, cond, eng=eng)
+        return x.clone()
+
+    two = six_steps()
+    eng.set_chains(1)
+    one = six_steps()
+    assert torch.equal(one, two)
+
+
 # ---------------------------------------------------------------- the device generator itself
 
 def test_device_gaussian_moments_and_ks():
@@ -297,15 +422,18 @@ def test_device_gaussian_streams_are_distinct():
 
 # ---------------------------------------------------------------- BASELINE batch size: B = 256, S = 64
 
-@pytest.mark.parametrize("kind", ["uncond", "cond"])
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
 def test_eps_at_bench_batch_size_vs_oracle(kind, precision):
     """BASELINE configs[1..3]'s batch: one 256-tile, 64x64 forward; four sampled tiles of it against the
-    oracle (per-forward bound of tests/test_gpu_parity.py) and slices of the batch bit for bit."""
+    oracle (per-forward bound of tests/test_gpu_parity.py) and slices of the batch bit for bit.  SR3 (configs[2]): the time input is
+    the continuous noise level, one fp32 per tile (src/hicdiff_sr3.py:634-637)."""
     B, S = 256, 64
     m, ref = product_unet(kind), oracle_unet(kind)
     x = tiles(256, B, S)
-    cond = tiles(257, B, S) if kind == "cond" else None
+    cond = tiles(257, B, S) if kind != "uncond" else None
     t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(8))
+    if kind == "sr3":
+        t = torch.rand((B, 1), generator=torch.Generator().manual_seed(8)) * 0.98 + 0.01
     xd, td, cd = x.cuda(), t.cuda(), None if cond is None else cond.cuda()
     full = m(xd, td, cd)
     pick = torch.tensor([0, 101, 200, 255])
@@ -314,6 +442,45 @@ def test_eps_at_bench_batch_size_vs_oracle(kind, precision):
     assert torch.equal(full, m(xd, td, cd))
     part = m(xd[96:160], td[96:160], None if cd is None else cd[96:160])
     assert torch.equal(full[96:160], part)
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
+def test_hicedrn_eps_at_bench_batch_size_vs_oracle(kind, precision):
+    """BASELINE configs[3]'s workload at its real grid: hicedrn on 256 tiles of 64x64 -- 4 096 M tiles x 2 N tiles of the 8-wave 256 x 128
+    kernel with eight K slices per tap, the grid `bench.py --workload hicedrn64` launches 65 times per step.  Three blocks keep the CPU
+    oracle in seconds; four sampled tiles against it, the whole batch bit for bit run to run, and a slice of the batch on its own."""
+    B, S = 256, 64
+    m, ref = product_hicedrn(kind, 3), oracle_hicedrn(kind, 3)
+    x = tiles(258, B, S)
+    cond = tiles(259, B, S) if kind != "uncond" else None
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(9))
+    if kind == "sr3":
+        t = torch.rand((B, 1), generator=torch.Generator().manual_seed(9)) * 0.98 + 0.01
+    xd, td, cd = x.cuda(), t.cuda(), None if cond is None else cond.cuda()
+    full = m(xd, td, cd)
+    pick = torch.tensor([0, 101, 200, 255])
+    want = oracle_once(("hicedrn3_b256", kind), lambda: ref(x[pick], t[pick], None if cond is None else cond[pick]))
+    assert rel_err(want, full[pick.cuda()]) < 1e-4
+    assert torch.equal(full, m(xd, td, cd))
+    part = m(xd[96:160], td[96:160], None if cd is None else cd[96:160])
+    assert torch.equal(full[96:160], part)
+
+
+def test_hicedrn32_at_bench_batch_size_properties_and_two_tiles_vs_oracle(precision):
+    """The network `bench.py --workload hicedrn64` times, all 32 blocks, on its 256 tiles: two sampled tiles against the oracle, the batch
+    bit for bit run to run, a slice on its own bit for bit."""
+    B, S = 256, 64
+    m, ref = product_hicedrn("uncond", 32), oracle_hicedrn("uncond", 32)
+    x = tiles(260, B, S)
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(10))
+    xd, td = x.cuda(), t.cuda()
+    full = m(xd, td)
+    assert bool(torch.isfinite(full).all())
+    pick = torch.tensor([7, 250])
+    want = oracle_once("hicedrn32_b256", lambda: ref(x[pick], t[pick], None))
+    assert rel_err(want, full[pick.cuda()]) < 1e-4
+    assert torch.equal(full, m(xd, td))
+    assert torch.equal(full[96:160], m(xd[96:160], td[96:160]))
 
 
 def test_hicedrn32_eps_at_64_vs_oracle(precision):

@@ -280,3 +280,13 @@ def test_oracle_objectives_pred_x0_and_pred_v_reproduce_the_reference():
         assert abs(float(ref.p_losses(g["x0"], g["t"], g["eps"])) - float(g[f"{obj}_loss"])) <= 1e-5 * float(g[f"{obj}_loss"])
         ddim = OD.DiffusionRef(model, image_size=40, timesteps=50, beta_schedule="linear", sampling_timesteps=5, ddim_sampling_eta=0.5, objective=obj)
         assert rel_err(g[f"{obj}_ddim_x0"], ddim.ddim_sample((2, 1, 40, 40), OD.TorchNoise(77))) < 1e-5
+
+
+def test_oracle_interpolate_reproduces_the_reference():
+    """GaussianDiffusion.interpolate (src/hicdiff.py:673-691): default (t = T - 1, lam = 0.5) and t = 20, lam = 0.3."""
+    from oracle import diffusion as OD
+    g = golden("interpolate")
+    ref = OD.DiffusionRef(oracle_unet("uncond"), image_size=40, timesteps=50, beta_schedule="linear", loss_type="l2")
+    for tag, t, lam, seed in (("default", None, 0.5, 611), ("t20_lam03", 20, 0.3, 612)):
+        got = ref.interpolate(g["x1"], g["x2"], OD.TorchNoise(seed), t=t, lam=lam)
+        assert rel_err(g[tag], got) < 1e-6, tag
