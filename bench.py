@@ -341,7 +341,7 @@ def main():
     ap.add_argument("--total-tiles", type=int, default=None,
                     help="strong-scaling form (BASELINE configs[3]: 256 hicedrn tiles sharded over the node): the job is this many tiles in all, "
                          "total/N per GPU; reported with \"scaling\": \"strong\"")
-    ap.add_argument("--chains", type=int, default=None, choices=[1, 2],
+    ap.add_argument("--chains", type=int, default=None, choices=[1, 2, 3, 4],
                     help="force one whole-batch chain or two half-batch chains per GPU (default: the library's rule, two from 512 k pixels per step on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
@@ -389,25 +389,36 @@ def main():
         eng.set_chains(args.chains)
     chains = eng.chains_for(B, S)
 
-    def run_steps(n, t):
-        """n reverse steps starting at timestep t (wrapping into a new chain below 0); returns the next t.  The steps run inside the
-        sampler's chain bracket (hicdiff_amd/_diffusion.py:_ancestral): the state meets this stream at the ends only."""
+    def run_ts(ts):
+        """One reverse step at each timestep of `ts`, inside the sampler's chain bracket (hicdiff_amd/_diffusion.py:_ancestral): the state
+        meets this stream at the ends only.  (A step's cost does not depend on the state it is given.)"""
         with eng.chain(B, S):
-            for _ in range(n):
+            for t in ts:
                 diff._step_inplace(img, t, cond, eng=eng)
-                t = t - 1 if t > 0 else T_CHAIN - 1
-        return t
 
-    # warm-up steps run at the END of a previous chain so that a --steps 1000 region is exactly t = 999 .. 0
-    t = run_steps(args.warmup, (args.warmup - 1) % T_CHAIN)
-    assert t == T_CHAIN - 1
+    def consecutive(n, t):
+        """n consecutive timesteps from t downwards (wrapping into a new chain below 0)."""
+        return [(t - i) % T_CHAIN for i in range(n)]
+
+    def spread(n):
+        """n timesteps spread evenly over the chain, t = 999 first: since round 4 a step's cost depends on the HALF of the chain it sits in
+        (the precision schedule), so K consecutive steps from t = 999 would time the cheaper half only.  The K-step
+        region is a stratified sample of the chain -- exactly the chain's mix for even K -- and `sustained` below is a whole chain."""
+        return [T_CHAIN - 1 - (i * T_CHAIN) // n for i in range(n)]
+
+    # set-up, not warm-up: the step's hipGraphs are captured on the second call of each arithmetic (engine.hip lane_step)
+    for t in (T_CHAIN - 1, 0):
+        run_ts([t, t, t])
+    timed = consecutive(T_CHAIN, T_CHAIN - 1) if args.steps >= T_CHAIN else spread(args.steps)
+    run_ts(spread(args.warmup))
     barrier()
     t0 = time.perf_counter()
-    t = run_steps(args.steps, t)
+    run_ts(timed)
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, device)
     sec_per_step = elapsed / args.steps
     value = (B * world) / (T_CHAIN * sec_per_step)
+    early = sum(1 for t in timed if diff._early_band(t))
 
     # Sustained rate: a whole chain (all ranks, same barriers), with HIP events on the launch stream after 20 steps
     # and at the end, so the first-20 burst and the steady state of the SAME run can be compared (clock give-back).
@@ -421,9 +432,9 @@ def main():
         barrier()
         s0 = time.perf_counter()
         ev[0].record()
-        t = run_steps(burst, T_CHAIN - 1)
+        run_ts(consecutive(burst, T_CHAIN - 1))
         ev[1].record()
-        t = run_steps(n_sus - burst, t)
+        run_ts(consecutive(n_sus - burst, T_CHAIN - 1 - burst))
         ev[2].record()
         barrier()
         sus_s = max_over_ranks(time.perf_counter() - s0, dist, device)
@@ -431,14 +442,15 @@ def main():
                      "tiles_per_s": round((B * world) / (T_CHAIN * sus_s / n_sus), 4),
                      "first_20_ms_per_step": round(ev[0].elapsed_time(ev[1]) / burst, 4),
                      "rest_ms_per_step": round(ev[1].elapsed_time(ev[2]) / max(n_sus - burst, 1), 4),
-                     "note": "one chain from t=999 timed after the K-step region (rank 0 events; ms_per_step is max over ranks, host clock)"}
+                     "note": "one chain from t=999 timed after the K-step region (rank 0 events; ms_per_step is max over ranks, host clock); "
+                             "first_20 lies in the early band of the precision schedule, so it is cheaper than the chain's mean"}
 
     # Roofline of the dominant kernel: the same step, launched eagerly with a HIP event pair around every
     # convolution launch on its stream (the timed region above replays a captured hipGraph of the step,
     # inside which per-launch events cannot be recorded).
-    prof_steps = max(1, min(args.steps, 5))
+    prof_steps = max(2, min(args.steps, 6) // 2 * 2)
     lib.hd_profile_enable(1)
-    t = run_steps(prof_steps, t)
+    run_ts(spread(prof_steps))
     barrier()
     rows_buf = (L.HdProfileRow * L.HD_PROFILE_MAX_ROWS)()
     n_rows = lib.hd_profile_read(rows_buf, L.HD_PROFILE_MAX_ROWS)
@@ -462,43 +474,57 @@ def main():
         assert full.shape[0] == B * world
 
     if rank == 0:
+        # A kernel's roofline follows its arithmetic: three bf16 MFMAs per product (2500 / 3), two fp16 MFMAs (2500 / 2: the early band's 3x3
+        # kernels), or the exact-fp32 MFMA.
+        def peak_of(name):
+            return PEAK_BF16_MFMA_TFLOPS / 2.0 if b"f16w2" in name else PEAK_BF16_MFMA_TFLOPS / 3.0 if b"bf16x3" in name else PEAK_F32_MFMA_TFLOPS
+
         dom = max(rows, key=lambda r: r.total_ms)
         ach = dom.flops / (dom.total_ms * 1e-3) / 1e12 if dom.total_ms > 0 else 0.0
-        split = b"bf16x3" in dom.kernel
-        peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if split else PEAK_F32_MFMA_TFLOPS
+        split = b"bf16x3" in dom.kernel or b"f16w2" in dom.kernel
+        peak = peak_of(dom.kernel)
         traffic, traffic_src = recorded_traffic(args.workload, dom.kernel.decode(), B, WORK[args.workload]["B"])
         whole_flops = w["flop"] * B / sec_per_step / 1e12
+        # the step's own MFMA roofline: the chain's mix of the two arithmetics over the timed steps (1x1 convolutions always take three products;
+        # priced with the 3x3 layers, i.e. slightly in the step's favour -- they are 5 % of the flops)
+        step_peak = (early * PEAK_BF16_MFMA_TFLOPS / 2.0 + (len(timed) - early) * PEAK_BF16_MFMA_TFLOPS / 3.0) / len(timed) if split else PEAK_F32_MFMA_TFLOPS
+        conv_ms = sum(r.total_ms for r in rows)
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom.bytes / max(dom.launches, 1)),
-            "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 MFMA 2500 / 3 MFMAs per product (split-bf16 x3)"
-                          if split else "exact-fp32 MFMA peak"),
+            "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 / fp16 MFMA 2500 / MFMAs per product (3: split-bf16 x3; 2: the early "
+                          "band's fp16 xh (wh + wl))" if split else "exact-fp32 MFMA peak"),
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),
             "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
-            "conv_time_share": round(sum(r.total_ms for r in rows) * 1e-3 / (prof_steps * sec_per_step), 4),
-            "all_convs_frac": round(sum(r.flops for r in rows) / max(sum(r.total_ms for r in rows) * 1e-3, 1e-12) / 1e12 / peak, 4),
+            "conv_time_share": round(conv_ms * 1e-3 / (prof_steps * sec_per_step), 4),
+            "all_convs_frac": round(sum(r.flops / peak_of(r.kernel) for r in rows) / max(conv_ms * 1e-3, 1e-12) / 1e12, 4),
             "profiled_steps": prof_steps,
             "whole_step": {
                 "algorithmic_TFLOPs": round(whole_flops, 1),
-                "frac_of_mfma_roofline": round(whole_flops / peak, 4),
+                "frac_of_mfma_roofline": round(whole_flops / step_peak, 4),
+                "mfma_roofline_TFLOPs": round(step_peak, 1),
                 "hbm_frac_algorithmic": round((w["act_bytes"] * B + w["w_bytes"]) / sec_per_step / 1e9 / PEAK_HBM_GBS, 4),
-                "note": "SURVEY 8(d) per-tile-step flops / bytes x tiles over the measured step time; MFMA roofline = the peak above, "
-                        "HBM = 8 TB/s (BASELINE target: hbm_frac_algorithmic >= 0.5)",
+                "note": "SURVEY 8(d) per-tile-step flops / bytes x tiles over the measured step time; MFMA roofline = the timed steps' mix of 2500/2 "
+                        "(early band) and 2500/3, HBM = 8 TB/s (BASELINE target: hbm_frac_algorithmic >= 0.5)",
             },
         }
         out = {
             "metric": "denoised Hi-C tiles/sec (1000-step reverse)", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.total_tiles else "weak", "vs_baseline": None,
-            "dtype": "f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate)" if split else "f32", "data": "synthetic",
+            "dtype": ("f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate" + ("; 3x3 convs of the steps t >= T/2: two fp16 MFMAs per product" if early else "") + ")")
+                     if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
                                    f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
                        "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
                        "chains": chains,
                        **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
-                       "timed_region": ("one whole chain, t = 999 .. 0" if args.steps == T_CHAIN else
-                                        f"{args.steps} consecutive steps from t = 999 (every step costs the same; see `sustained`)")},
+                       "precision_schedule": (f"3x3 convs: two fp16 products per multiply for t >= {int(diff.early_band_from * T_CHAIN)}, split-bf16 x3 below "
+                                              f"({early} of the {len(timed)} timed steps in the early band)" if early else "split-bf16 x3 at every step"),
+                       "timed_region": ("one whole chain, t = 999 .. 0" if args.steps >= T_CHAIN else
+                                        f"{args.steps} steps spread evenly over the chain, t = 999, {timed[1] if len(timed) > 1 else 999}, ... (a stratified sample: "
+                                        "the two halves of the chain cost differently; see `sustained` for a whole chain)")},
             "roofline": roofline,
         }
         if sustained is not None:

@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import contextlib
 import math
+import os
 from collections import namedtuple
 from typing import Optional
 
@@ -130,6 +131,12 @@ class DiffusionCore(nn.Module):
         self.unnormalize = (lambda t: (t + 1) * 0.5) if auto_normalize else (lambda t: t)
 
         # sampling knobs that do not exist upstream
+        # Precision schedule of the ancestral chain: in the first half of a long chain (t >= T / 2, T >= 500) the
+        # UNet's 3x3 convolutions run on two fp16 products per multiply instead of three bf16 ones -- the chain damps what that costs
+        # (tests/studies/error_budget_study.py; tests/test_gpu_timed_path.py::test_full_length_chain_drift_vs_oracle holds the bound).
+        # False: split-bf16 x3 at every step.  HICDIFF_EARLY_F16=0 turns it off for a process.
+        self.early_band_f16 = os.environ.get("HICDIFF_EARLY_F16", "1") != "0"
+        self.early_band_from = 0.5   # the band is t >= early_band_from * T (measured: profiles/r04_e_early_band_drift.txt)
         self.noise_source = None     # None: device Philox; or an object with .randn(shape) -> device tensor
         self.seed = 1234             # Philox key for device noise
         self.tile_offset = 0         # global index of this rank's first tile (sharded sampling)
@@ -227,7 +234,15 @@ class DiffusionCore(nn.Module):
             c.time_value = float(np.float32(self.sqrt_alphas_cumprod_prev[t_idx + 1].item()))
         else:
             c.time_value = float(t_idx)
+        c.arith = L.HD_ARITH_F16W2 if self._early_band(t_idx) else L.HD_ARITH_DEFAULT
         return c
+
+    def _early_band(self, t_idx: int) -> bool:
+        """Does step t take the two-product arithmetic?  Long chains only (the 50-step chains amplify a per-step error 4-7 x more: each of
+        their steps is twenty steps' worth of posterior_mean_coef1), their first half only, and networks that declare EARLY_BAND_OK (the UNet: what
+        the CPU study and the GPU drift runs covered)."""
+        T = self.num_timesteps
+        return bool(self.early_band_f16) and T >= 500 and t_idx >= int(self.early_band_from * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
 
     def _step_inplace(self, img, t_idx: int, cond, x0_out=None, eng=None):
         """img <- p_sample(img, t): one hd_ddpm_step call (eps-net + clamp + posterior + noise).  The three objectives differ only in the two
@@ -403,12 +418,11 @@ class DiffusionCore(nn.Module):
             return tr.loss_backward(x_start, cond, level, noise, level, (1 - level ** 2).sqrt(), self.loss_type == "l2")
         if self.__dict__.get("_p2_is_one") is None:                      # checked once: it costs a device -> host read
             self.__dict__["_p2_is_one"] = float(self.p2_loss_weight.min()) == 1.0 and float(self.p2_loss_weight.max()) == 1.0
-        if not self.__dict__["_p2_is_one"]:
-            raise NotImplementedError("p2_loss_weight_gamma != 0 is not used by the reference's training")
         tr = trainer_for(self.model, x_start.shape[0], x_start.shape[-1])
         a_t = self.sqrt_alphas_cumprod.gather(-1, t)
         s_t = self.sqrt_one_minus_alphas_cumprod.gather(-1, t)
-        return tr.loss_backward(x_start, cond, t, noise, a_t, s_t, self.loss_type == "l2", self.objective)      # target: _target's (src/hicdiff.py:733-741)
+        lw = None if self.__dict__["_p2_is_one"] else self.p2_loss_weight.gather(-1, t)      # p2_loss_weight_gamma != 0 (src/hicdiff.py:522,746)
+        return tr.loss_backward(x_start, cond, t, noise, a_t, s_t, self.loss_type == "l2", self.objective, lw)      # target: _target's (src/hicdiff.py:733-741)
 
     def _target(self, x_start, t, noise):
         if self.objective == "pred_noise":

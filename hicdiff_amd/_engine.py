@@ -93,7 +93,8 @@ class Engine:
         self._reserved = (B2, S2)
 
     def set_precision(self, mode: int):
-        """L.HD_PRECISION_F32 (exact fp32 MFMA) or L.HD_PRECISION_BF16X3 (default, split-bf16 x3)."""
+        """L.HD_PRECISION_F32 (exact fp32 MFMA), L.HD_PRECISION_BF16X3 (default, split-bf16 x3) or L.HD_PRECISION_F16W2 (BF16X3 with two
+        fp16 products in the 3x3 convolutions: the early band's arithmetic as a context-wide mode, for tests and measurements)."""
         self._check(self.lib.hd_set_precision(self.ctx, int(mode)))
         self.precision = int(mode)
 

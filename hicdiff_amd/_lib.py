@@ -16,7 +16,8 @@ LIB_PATH = os.environ.get("HICDIFF_HIP_LIB") or os.path.join(_HERE, "libhicdiff_
 HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -4, -5
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
-HD_PRECISION_F32, HD_PRECISION_BF16X3 = 0, 1
+HD_PRECISION_F32, HD_PRECISION_BF16X3, HD_PRECISION_F16W2 = 0, 1, 2
+HD_ARITH_DEFAULT, HD_ARITH_F16W2 = 0, 1      # hd_ddpm_coef.arith
 HD_TRAIN_PREC_BF16 = 2
 HD_PROFILE_MAX_ROWS = 96
 
@@ -49,7 +50,7 @@ class HdDdpmCoef(_Prefixed):
         ("struct_bytes", C.c_uint32),
         ("sqrt_recip_alphas_cumprod", C.c_float), ("sqrt_recipm1_alphas_cumprod", C.c_float),
         ("posterior_mean_coef1", C.c_float), ("posterior_mean_coef2", C.c_float),
-        ("sigma", C.c_float), ("time_value", C.c_float), ("eps_coef", C.c_float),
+        ("sigma", C.c_float), ("time_value", C.c_float), ("eps_coef", C.c_float), ("arith", C.c_uint32),
     ]
 
 
@@ -58,6 +59,7 @@ class HdDdrmCoef(_Prefixed):
         ("struct_bytes", C.c_uint32),
         ("sqrt_at", C.c_float), ("sqrt_1m_at", C.c_float), ("sqrt_at_next", C.c_float), ("sigma_next", C.c_float),
         ("sigma_0", C.c_float), ("etaA", C.c_float), ("etaB", C.c_float), ("etaC", C.c_float), ("time_value", C.c_float),
+        ("skip_network", C.c_uint32),
     ]
 
 
@@ -97,6 +99,7 @@ SYMBOLS = {
     "hd_train_last_error": (C.c_char_p, [_P]),
     "hd_train_set_precision": (C.c_int, [_P, C.c_int]),
     "hd_train_set_objective": (C.c_int, [_P, C.c_int]),
+    "hd_train_set_loss_weights": (C.c_int, [_P, _P]),
     "hd_train_param_count": (C.c_int, [_P, _P]),
     "hd_train_param_slot": (C.c_int, [_P, C.c_int, _P, _P, _P, _P]),
     "hd_train_stage_count": (C.c_int, [_P]),

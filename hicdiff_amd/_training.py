@@ -176,8 +176,13 @@ class NativeTrainer:
             n *= s
         return self.grads[off:off + n].view(shape)
 
-    def loss_backward(self, x_start, cond, t, noise, a_t, s_t, l2: bool, objective: str = "pred_noise"):
+    def loss_backward(self, x_start, cond, t, noise, a_t, s_t, l2: bool, objective: str = "pred_noise", loss_weights=None):
+        """loss_weights: per-sample weights of the loss (p2_loss_weight[t], src/hicdiff.py:746), or None for the plain mean."""
         B, _, S, _ = x_start.shape
+        self._lw = None if loss_weights is None else loss_weights.detach().to(torch.float32).contiguous()      # kept alive until the next call
+        rc = self.lib.hd_train_set_loss_weights(self.h, None if self._lw is None else C.c_void_p(self._lw.data_ptr()))
+        if rc != 0:
+            raise L.HdError(rc, (self.lib.hd_train_last_error(self.h) or b"").decode())
         if objective != getattr(self, "objective", "pred_noise"):
             rc = self.lib.hd_train_set_objective(self.h, {"pred_noise": 0, "pred_x0": 1, "pred_v": 2}[objective])
             if rc != 0:
@@ -208,6 +213,9 @@ class NativeTrainer:
         if _dist_world() > 1 and os.environ.get("HICDIFF_DP_OVERLAP", "1") != "0":
             # every kernel of the step is queued; queue the per-stage sums behind their events now, so that stage k travels over xGMI
             # while stages k+1.. are still being computed.  (HICDIFF_DP_OVERLAP=0: one all-reduce of the whole buffer in Adam.step.)
+            # REQUIREMENT: the collectives are issued HERE, in the forward call -- unlike DDP, which communicates in backward() -- so under
+            # torchrun every rank must make the same sequence of train-mode, grad-enabled `diffusion(x)` calls (no rank-0-only loss probe,
+            # equal batch counts per epoch: train.py trims ragged shards).  Evaluate under torch.no_grad() / .eval() for anything else.
             if self.reducer is None:
                 self.reducer = StagedReducer(self.grads, self.slots, self.slot_stage)
             with torch.cuda.device(self.device):
@@ -266,6 +274,7 @@ def trainer_for(model, B: int, S: int) -> NativeTrainer:
     tr = model.__dict__.get("_hd_trainer")
     if tr is None or (tr.B, tr.S) != (B, S) or tr.device != next(model.parameters()).device or not tr.still_seated() or tr.precision != precision:
         if tr is not None:
+            tr.reduce_finish()          # a staged reduction of the old trainer's last loss may still be writing its gradient buffer
             for p in tr.params:
                 p.grad = None
         tr = NativeTrainer(model, B, S, precision)

@@ -8,6 +8,8 @@ from ._specs import unet_specs
 
 
 class UnetBase(EpsNetBase):
+    EARLY_BAND_OK = True      # the samplers' precision schedule applies (hicdiff_amd/_diffusion.py:_early_band; measured: profiles/r04_e_*)
+
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1, self_condition=False,
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, noise_level_emb=False):

@@ -63,6 +63,7 @@
 enum { IN_AFFINE_SILU_E = 3 };   // kernel-side mode: IN_AFFINE_SILU with the additive term inE (SR3 blocks)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -76,6 +77,13 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     }
     hi = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
     lo = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+}
+
+// eight fp32 -> eight fp16 (round to nearest even), packed like split8's halves
+__device__ __forceinline__ uint4 half8(const float4& a, const float4& b) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto pk = [](float x, float y) { const h2 v = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(unsigned, v); };
+    return make_uint4(pk(a.x, a.y), pk(a.z, a.w), pk(b.x, b.y), pk(b.z, b.w));
 }
 
 // loader transform on 4 channels; pt: this item's entry of the slice's parameter table in LDS
@@ -118,7 +126,10 @@ __device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
 
 // WM x WN waves, each TM x TN accumulator tiles of 32 x 32; MAXI = staged 8-channel items per thread;
 // NTAPS = 9: 3x3 filter, taps unrolled; NTAPS = 0: any filter (1x1, 2x2 stride 2, ...), taps in a loop.
-// PLAIN: one bf16 MFMA per product (hi x hi only) -- the optional bf16 arithmetic of the training step; the staging is unchanged.
+// AR (arithmetic of a product): 0 = split-bf16 x3 (hi hi + hi lo + lo hi); 1 = PLAIN, one bf16 MFMA (hi x hi only) -- the optional bf16
+// arithmetic of the training step; 2 = F16W2 (round 4), two fp16 MFMAs xh (wh + wl): the activation is rounded ONCE to fp16 (11 significant
+// bits), the weight image holds fp16 hi | lo of the exact weight -- a third fewer MFMAs and no lo half of the window, for the timestep band
+// whose error the chain damps (tests/studies/error_budget_study.py).  The staging layout is the same in all three.
 #ifndef HD_CK16_CAP3
 #define HD_CK16_CAP3 1    // 1: the plain-loader 256 x 64 tile with 16-channel slices is capped at 168 registers (three workgroups per CU)
 #endif
@@ -127,8 +138,11 @@ constexpr bool conv_cap3() { return HD_CK16_CAP3 && NTAPS == 9 && CK == 16 && WM
 #ifndef HD_CONV_XD2
 #define HD_CONV_XD2 1     // any-filter kernels: two activation prefetch register sets (0: one, the round-2 form; A/B builds)
 #endif
-template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN, bool FBWD = false>
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, int AR, bool FBWD = false>
 __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
+    constexpr bool F16 = AR == 2;
+    constexpr bool ALO = AR == 0;                      // the window carries a lo half
+    constexpr bool BLO = AR != 1;                      // the weight fragments carry a lo half
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr bool M16 = CK == 32 && NTAPS == 9 && HD_MFMA16;   // 16 x 16 x 32 MFMA tiles (one instruction covers the whole 32-channel slice); the 1x1 kernels measured 5-12 % slower on it
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = M16 ? 160 : 4 * CK + 16;
@@ -374,11 +388,12 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         float4 v1 = xform4<MODE>(xr[Q][j][1], pt + 16, ptv, ln_mu[j], ln_rs[j]);
         if constexpr (MODE == IN_SOFTMAX32) softmax32(v0, v1);
         uint4 hi, lo;
-        split8(v0, v1, hi, lo);
+        if constexpr (F16) { hi = half8(v0, v1); lo = hi; }
+        else split8(v0, v1, hi, lo);
         if (it_pad[j]) { hi = make_uint4(0, 0, 0, 0); lo = hi; }   // zero padding is applied AFTER the transform
         char* d = xdst + it_dst[j];
         *reinterpret_cast<uint4*>(d) = hi;
-        if constexpr (!PLAIN) *reinterpret_cast<uint4*>(d + 2 * CK) = lo;      // (PLAIN: the lo half of the split is dead code)
+        if constexpr (ALO) *reinterpret_cast<uint4*>(d + 2 * CK) = lo;      // (PLAIN / F16W2: the lo half is dead code)
     };
     auto x_stage = [&](int j, int c, char* xdst) { x_stage_s(X0{}, j, c, xdst); };
     auto slice_src = [&](int c, const float*& src, int& Csrc) {  // channel-concatenated input: two tensors
@@ -394,7 +409,7 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         for (int tm = 0; tm < TMF; ++tm) {
             const char* a = Xc + aoff[tm] + off;
             f.h[tm] = *reinterpret_cast<const bf16x8*>(a);
-            if constexpr (!PLAIN) f.l[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
+            if constexpr (ALO) f.l[tm] = *reinterpret_cast<const bf16x8*>(a + 2 * CK);
         }
     };
     auto ld_b = [&](FragB& f, int slot) {
@@ -402,12 +417,18 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         for (int tn = 0; tn < TNF; ++tn) {
             const char* b = Ws + slot * SLAB16;
             f.h[tn] = *reinterpret_cast<const bf16x8*>(b + boff[tn]);
-            if constexpr (!PLAIN) f.l[tn] = *reinterpret_cast<const bf16x8*>(b + (boff[tn] ^ 32));
+            if constexpr (BLO) f.l[tn] = *reinterpret_cast<const bf16x8*>(b + (boff[tn] ^ 32));
         }
     };
     auto mma = [](const bf16x8& a, const bf16x8& b, const AccT& c) {
-        if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        if constexpr (F16) {                           // the same 16 bytes per fragment, read as fp16
+            const f16x8 ah = __builtin_bit_cast(f16x8, a), bh = __builtin_bit_cast(f16x8, b);
+            if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, c, 0, 0, 0);
+        } else {
+            if constexpr (M16) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+            else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        }
     };
     auto mm = [&](const FragA& a, const FragB& b) {
         if (ABL(8)) return;
@@ -415,10 +436,8 @@ __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
         for (int tm = 0; tm < TMF; ++tm)
 #pragma unroll
             for (int tn = 0; tn < TNF; ++tn) {
-                if constexpr (!PLAIN) {
-                    acc[tm][tn] = mma(a.l[tm], b.h[tn], acc[tm][tn]);
-                    acc[tm][tn] = mma(a.h[tm], b.l[tn], acc[tm][tn]);
-                }
+                if constexpr (ALO) acc[tm][tn] = mma(a.l[tm], b.h[tn], acc[tm][tn]);
+                if constexpr (BLO) acc[tm][tn] = mma(a.h[tm], b.l[tn], acc[tm][tn]);
                 acc[tm][tn] = mma(a.h[tm], b.h[tn], acc[tm][tn]);
             }
     };
@@ -666,16 +685,22 @@ template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 // the 128 x 128 variants with 16-channel slices everywhere measured a loss: 14.1 vs 13.45 ms per unet64 step.)
 // Only the plain loader fits 168 registers without scratch (the GroupNorm-apply loaders need 196: capped, they spill 12 registers -- tests/test_isa_guards.py).
 __global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>() ? 3 : (NTAPS == 0 && MAXI > 4) ? 1 : 2)) void conv_igemm_bf16x3_kernel(ConvKArgs p) {
-    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, false>(p);
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, 0>(p);
+}
+// two fp16 products per multiply, xh (wh + wl): the 3x3 kernels only (the any-filter kernels are not MFMA-bound)
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
+__global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>() ? 3 : 2)) void conv_igemm_f16w2_kernel(ConvKArgs p) {
+    static_assert(NTAPS == 9, "3x3 kernels only");
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, 2>(p);
 }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(ConvKArgs p) {
-    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, true>(p);
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, 1>(p);
 }
 // training only: the same bodies with the EP_FILM_SILU_BWD epilogue mode compiled in (PLAIN: the bf16 option's one-product form)
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, bool PLAIN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16x3_fbwd_kernel(ConvKArgs p) {
-    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, PLAIN, true>(p);
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, PLAIN ? 1 : 0, true>(p);
 }
 
 template <typename K>

@@ -326,6 +326,11 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.out = a.out; k.pre_out = a.pre_out;
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     k.plain = a.plain_bf16;
+    // two fp16 products per multiply: 3x3 layers that carry the fp16 image, shared weights, none of the training-only forms
+    k.f16w2 = a.f16w2 && a.cw.wsplit16 && a.cw.KH == 3 && a.cw.KW == 3 && !a.w_bstride && !a.plain_bf16 && !(a.ep & EP_FILM_SILU_BWD) &&
+              a.in_mode != IN_LAYERNORM && a.in_mode != IN_SOFTMAX32 && !(a.in_mode == IN_AFFINE_SILU && a.inE) && a.precision == HD_PREC_BF16X3;
+    // (the SR3 blocks' loader with the additive term keeps three products: its 256 x 64 instantiation does not fit the registers without scratch)
+    if (k.f16w2) k.wsplit = a.cw.wsplit16;
     k.m16 = 0;
     static const int ablate = getenv("HICDIFF_ABLATE") ? atoi(getenv("HICDIFF_ABLATE")) : 0;
     k.ablate = ablate;
@@ -447,8 +452,10 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 
 // packed fp32 [taps][Cin][CoutPad] -> split bf16 [taps][Cin/CK][CoutPad][CK hi | CK lo].  The bf16x3 convolution kernels read CK = 16
 // images only (their weights travel in 16-channel k-steps whatever the activation slice is); CK = 32 serves the training side's GEMMs.
+// f16 != 0: fp16 hi | lo instead (the two-product arithmetic's image: hi = fp16(w), lo = fp16(w - hi), subnormals kept -- the fp16 MFMAs
+// honour them, tools/mfma_f16_denorm_probe.hip).
 __global__ __launch_bounds__(256) void split_conv_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int taps,
-                                                         int Cin, int CoutPad, int CK) {
+                                                         int Cin, int CoutPad, int CK, int f16) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)taps * Cin * CoutPad;
     if (i >= total) return;
@@ -457,9 +464,16 @@ __global__ __launch_bounds__(256) void split_conv_kernel(const float* __restrict
     const int tap = (int)(i / ((size_t)CoutPad * Cin));
     const int c = cin / CK, kl = cin - c * CK;
     const float v = w[i];
+    unsigned short* row = dst + (((size_t)tap * (Cin / CK) + c) * CoutPad + n) * (2 * CK);
+    if (f16) {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        row[kl] = __builtin_bit_cast(unsigned short, hi);
+        row[CK + kl] = __builtin_bit_cast(unsigned short, lo);
+        return;
+    }
     const __bf16 hi = (__bf16)v;
     const __bf16 lo = (__bf16)(v - (float)hi);
-    unsigned short* row = dst + (((size_t)tap * (Cin / CK) + c) * CoutPad + n) * (2 * CK);
     row[kl] = __builtin_bit_cast(unsigned short, hi);
     row[CK + kl] = __builtin_bit_cast(unsigned short, lo);
 }
@@ -473,9 +487,9 @@ int launch_pack_conv(const float* src, float* dst, int Cout, int Cin, int KH, in
     return 0;
 }
 
-int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st) {
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16) {
     const size_t total = (size_t)taps * Cin * CoutPad;
-    hipLaunchKernelGGL(split_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, dst, taps, Cin, CoutPad, CK);
+    hipLaunchKernelGGL(split_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, dst, taps, Cin, CoutPad, CK, f16);
     return 0;
 }
 

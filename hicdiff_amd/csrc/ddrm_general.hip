@@ -200,10 +200,12 @@ int hd_ddrm_x0(const float* x, const float* eps, float sqrt_at, float sqrt_1m_at
 }
 
 int hd_ddrm_general_update(const float* vt_x0, const float* vt_et, const float* ut_y, const float* singulars, int M, const float* z0,
-                           const float* z1, const float* z2, const hd_ddrm_coef* c, float* out, int B, int D, uint64_t seed,
+                           const float* z1, const float* z2, const hd_ddrm_coef* cin, float* out, int B, int D, uint64_t seed,
                            uint64_t tile_offset, uint32_t step, void* stream) {
-    if (!vt_x0 || !vt_et || !out || !c || B < 1 || D < 4 || D % 4 || M < 0 || M > D || (M > 0 && (!ut_y || !singulars))) return HD_EINVAL;
-    if (c->struct_bytes != sizeof(hd_ddrm_coef)) { hd_set_error("hd_ddrm_coef: struct_bytes must be sizeof(hd_ddrm_coef)"); return HD_EINVAL; }   // size-prefixed struct (hicdiff_hip.h)
+    if (!vt_x0 || !vt_et || !out || !cin || B < 1 || D < 4 || D % 4 || M < 0 || M > D || (M > 0 && (!ut_y || !singulars))) return HD_EINVAL;
+    hd_ddrm_coef kk;                      // size-prefixed struct (hicdiff_hip.h): the same rule as hd_ddrm_step
+    if (!hd_read_prefixed(cin, sizeof(hd_ddrm_coef), &kk)) { hd_set_error("hd_ddrm_coef: struct_bytes is not a size this library knows"); return HD_EINVAL; }
+    const hd_ddrm_coef* c = &kk;
     hipLaunchKernelGGL(ddrm_general_update_kernel, dim3((unsigned)(((size_t)B * (D / 4) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vt_x0, vt_et,
                        ut_y, singulars, M, D, z0, z1, z2, c->sigma_next, c->sigma_0, c->etaA, c->etaB, c->etaC, c->sqrt_at_next, out, B, seed,
                        tile_offset, step);
@@ -227,8 +229,7 @@ int hd_kvec_matmul(const float* src, const float* mat, float* dst, size_t N, int
 int hd_sandwich_matmul(const float* A, const float* x, const float* Bm, float* dst, int n, int S, void* stream) {
     if (!A || !x || !Bm || !dst || n < 0 || S < 1 || S > 64 || x == dst) return HD_EINVAL;
     if (n == 0) return HD_OK;
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute((const void*)sandwich_matmul_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); raised = true; }
+    if (!hd_raise_dynamic_lds((const void*)sandwich_matmul_kernel, 64 * 1024)) { hd_set_error("sandwich_matmul: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return HD_EHIP; }
     hipLaunchKernelGGL(sandwich_matmul_kernel, dim3(n), dim3(256), (size_t)4 * S * S * sizeof(float), (hipStream_t)stream, A, x, Bm, dst, S);
     return check("sandwich_matmul");
 }

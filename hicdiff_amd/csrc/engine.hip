@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -112,6 +114,7 @@ struct hd_ctx {
     float* eps_buf = nullptr; size_t eps_cap = 0;   // eps of the fused step calls
     int resB = 0, resS = 0;
     int precision = HD_PREC_BF16X3;   // arithmetic of the wide convolutions (hd_set_precision)
+    int f16w2 = 0;                    // with BF16X3: the 3x3 convolutions take two fp16 products per multiply (HD_PRECISION_F16W2, or one step's hd_ddpm_coef.arith)
     int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
     // hipGraph replay of the fused sampler steps (device-generated noise only): one graph per
     // (kind, B, S, tensor addresses); the step's scalars are written to the lane's `sp_dev` by a 1-thread kernel.
@@ -130,10 +133,11 @@ struct hd_ctx {
         bool dirty = false;        // holds work the caller's stream has not been ordered after yet (chain bracket)
         void drop_graphs() { for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); graphs.clear(); }
     };
-    Lane lane[2];
+    static constexpr int MAX_LANES = 4;
+    Lane lane[MAX_LANES];
     hipEvent_t ev_in = nullptr;
     int use_graphs = -1;           // 1 / 0: always / never replay the fused steps from a hipGraph; -1 (default): by the amount of work, see run_step
-    int chains = -1;               // 2 / 1: always / never cut a replayed step into two half-batch lanes; -1 (default): by the amount of work, see lanes_for
+    int chains = -1;               // n >= 1: always cut a replayed step into n sub-batch lanes (1: never); -1 (default): by the amount of work, see lanes_for
     int lane_delay_us = 0;         // experiment knob (HICDIFF_LANE_DELAY_US): lane 1 starts a chain this much later than lane 0
     bool in_chain = false;         // between hd_chain_begin and hd_chain_end
     bool forked = false;           // in_chain: the lanes already wait behind the caller's stream
@@ -194,6 +198,16 @@ struct Loader {
         }
         // the split image is packed in 16-channel k-steps whatever the kernel's activation slice (w->ck) is: conv_bf16x3_kernel.h
         HD_TRY(launch_split_conv(w->w, w->wsplit, KH * KH, cin, w->CoutPad, 16, st));
+        // 3x3 filters also as fp16 hi | lo: the two-product arithmetic of the early timestep band (hd_ddpm_coef.arith; conv_bf16x3_kernel.h AR = 2)
+        if (KH == 3 && !unshuffle && cin % 16 == 0) {
+            if (!w->wsplit16) {
+                void* p = nullptr;
+                if (hipMalloc(&p, (size_t)9 * cin * w->CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
+                c->owned.push_back(p);
+                w->wsplit16 = (unsigned short*)p;
+            }
+            HD_TRY(launch_split_conv(w->w, w->wsplit16, 9, cin, w->CoutPad, 16, st, 1));
+        }
         // Winograd image of the 3x3 filters (conv_winograd.hip): only while that opt-in path is switched on (HICDIFF_WINOGRAD=1 / hd_debug_winograd(1)
         // before the weights are loaded) -- the image is 16/9 of the filter bytes twice over and one more pack launch per layer; without it
         // conv_uses_winograd() is false and the layer takes the implicit-GEMM kernel
@@ -407,6 +421,7 @@ static void pick_slices(ConvArgs& a) {
 static int run_conv(Run& r, ConvArgs& a) {
     pick_slices(a);
     a.precision = r.c->precision;
+    a.f16w2 = r.c->f16w2;
     // the dry run sizes the workspace for either arithmetic (hd_set_precision may switch later): plan the split as the fast path would
     ConvArgs probe = a; probe.precision = HD_PREC_BF16X3;
     const int ks = conv_splitk(probe);
@@ -425,6 +440,7 @@ static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* 
     const int HW = a.H * a.W;
     pick_slices(a);
     a.precision = r.c->precision;
+    a.f16w2 = r.c->f16w2;
     int slots = conv_gn_slots(a);
     const bool fused = slots > 0;
     if (!fused) slots = (HW + 255) / 256;
@@ -747,21 +763,21 @@ static int forward(hd_ctx* c, const float* x, const void* t, int t_kind, float t
     return rc;
 }
 
-// A size-prefixed struct of the ABI (include/hicdiff_hip.h) -> a zero-filled copy of this build's revision.  Exactly `struct_bytes` bytes of
-// the caller's memory are read; sizes this build does not know -- a struct from a binding without the prefix shows up here as the bit
-// pattern of its first float -- are refused, never read past.
-template <typename T>
-static bool read_prefixed(const T* src, size_t oldest_bytes, T* dst) {
-    uint32_t n;
-    memcpy(&n, src, sizeof(n));
-    if (n < oldest_bytes || n > sizeof(T) || n % 4) return false;
-    memset(dst, 0, sizeof(T));
-    memcpy(dst, src, n);
-    return true;
-}
 static const char* const kCoefSizeMsg =
     "coefficient struct: struct_bytes is not a size this library knows (set it to sizeof of your struct; bindings written before ABI revision 3 "
     "lack the field -- see include/hicdiff_hip.h)";
+
+bool hd_raise_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    done.insert({dev, kernel});
+    return true;
+}
 
 // ---- C ABI -------------------------------------------------------------------------------------
 extern "C" {
@@ -791,7 +807,7 @@ int hd_create(hd_ctx** out, int device, const hd_arch_desc* a) {
     c->ck = (a->dim % 32 == 0) ? 32 : 16;
     if (const char* k = getenv("HICDIFF_CK")) { if (atoi(k) == 16) c->ck = 16; }   // tuning experiments
     if (const char* g = getenv("HICDIFF_GRAPHS")) c->use_graphs = atoi(g) != 0 ? 1 : 0;
-    if (const char* g = getenv("HICDIFF_CHAINS")) c->chains = atoi(g) >= 2 ? 2 : 1;
+    if (const char* g = getenv("HICDIFF_CHAINS")) c->chains = std::max(1, std::min(atoi(g), (int)hd_ctx::MAX_LANES));
     if (const char* g = getenv("HICDIFF_LANE_DELAY_US")) c->lane_delay_us = std::max(0, std::min(atoi(g), 100000));
     if (const char* e = getenv("HICDIFF_PRECISION")) c->precision = (std::string(e) == "f32") ? HD_PREC_F32 : HD_PREC_BF16X3;
     if (a->kind == HD_ARCH_UNET) { c->first_ks = 7; c->first_cout = a->dim; c->film_n = unet_film_total(*a); }
@@ -830,13 +846,12 @@ int hd_load_weights(hd_ctx* c, const hd_named_tensor* tensors, int n, void* stre
 }
 
 // How a replayed step of B tiles of S x S is cut: two half-batch lanes from 512 k pixels per step on (measured: profiles/r04_a_*), one
-// whole-batch lane below.  A rule by the amount of work only; the halves are even so that kernels that pair images keep their pairs.
+// whole-batch lane below.  A rule by the amount of work only; sub-batches start at even tiles so that kernels that pair images keep their pairs.
 static int lanes_for(const hd_ctx* c, int B, int S) {
-    if (B < 4) return 1;
-    if (c->chains >= 0) return c->chains >= 2 ? 2 : 1;
-    return (long long)B * S * S >= 524288 ? 2 : 1;
+    if (c->chains >= 0) return std::max(1, std::min(c->chains, B / 2));
+    return B >= 4 && (long long)B * S * S >= 524288 ? 2 : 1;
 }
-static int lane_first(int B) { return (B / 2 + 1) & ~1; }      // tiles of lane 0; lane 1 takes the rest
+static int lane_start(int B, int n, int i) { return i >= n ? B : (int)(((long long)B * i / n + 1) & ~1LL); }      // first tile of lane i of n
 
 static int dry_bytes(hd_ctx* c, int B, int S, size_t* out) {
     // A first-fit pool replays a plan only if it was sized with that plan: the allocations differ between the two arithmetic modes
@@ -889,13 +904,12 @@ int hd_reserve(hd_ctx* c, int B, int S) {
     if (hipSetDevice(c->device) != hipSuccess) return fail(c, HD_EHIP, "hipSetDevice failed");
     bool synced = false;
     HD_TRY(grow_block(c, c->pool, need, &synced));
-    if (lanes_for(c, B, S) == 2) {
-        const int b0 = lane_first(B);
-        size_t n0 = 0, n1 = 0;
-        HD_TRY(dry_bytes(c, b0, S, &n0));
-        HD_TRY(dry_bytes(c, B - b0, S, &n1));
-        HD_TRY(grow_block(c, c->lane[0].pool, n0, &synced));
-        HD_TRY(grow_block(c, c->lane[1].pool, n1, &synced));
+    if (const int nl = lanes_for(c, B, S); nl > 1) {
+        for (int i = 0; i < nl; ++i) {
+            size_t ni = 0;
+            HD_TRY(dry_bytes(c, lane_start(B, nl, i + 1) - lane_start(B, nl, i), S, &ni));
+            HD_TRY(grow_block(c, c->lane[i].pool, ni, &synced));
+        }
     }
     const size_t en = (size_t)B * S * S;
     if (en > c->eps_cap) {
@@ -957,13 +971,14 @@ static int lanes_join(hd_ctx* c, hipStream_t user) {
 static int lane_step(hd_ctx* c, hd_ctx::Lane& L, Pool* pool, int kind, float* x, const float* aux, const StepParams& v, float* x0_out, float* eps,
                      int B, int S) {
     hd_ctx::StepGraph* g = nullptr;
-    for (auto& e : L.graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == c->precision && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
+    const int arith = c->precision == HD_PREC_BF16X3 && c->f16w2 ? 2 : c->precision;     // a captured step holds the kernels of the arithmetic it was captured under
+    for (auto& e : L.graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == arith && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
     if (!g) {
         if (L.graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
             if (L.graphs.front().exec) (void)hipGraphExecDestroy(L.graphs.front().exec);
             L.graphs.erase(L.graphs.begin());
         }
-        L.graphs.push_back({kind, B, S, c->precision, x, aux, x0_out, 0, nullptr});
+        L.graphs.push_back({kind, B, S, arith, x, aux, x0_out, 0, nullptr});
         g = &L.graphs.back();
     }
     HD_TRY(launch_set_step_params(L.sp_dev, v, L.st));
@@ -1000,28 +1015,29 @@ static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float
     }
     HD_TRY(lanes_setup(c));
     int nl = lanes_for(c, B, S);
-    const int b0 = nl == 2 ? lane_first(B) : B;
-    if (nl == 2 && (c->lane[0].pool.cap == 0 || c->lane[1].pool.cap == 0)) nl = 1;    // reserved before hd_set_chains(2): whole-batch lane
+    for (int i = 0; i < nl && nl > 1; ++i)
+        if (c->lane[i].pool.cap == 0) { nl = 1; break; }      // reserved before hd_set_chains(n): whole-batch lane
     // order after the caller's stream (every step; inside a chain bracket only at its first replayed step), run on the lanes, hand back
     if (!c->in_chain || !c->forked) {
         if (hipEventRecord(c->ev_in, user) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
         for (auto& L : c->lane) if (hipStreamWaitEvent(L.st, c->ev_in, 0) != hipSuccess) return fail(c, HD_EHIP, "stream hand-off failed");
         if (c->in_chain) {
             c->forked = true;
-            if (nl == 2 && c->lane_delay_us > 0) HD_TRY(launch_spin_us(c->lane_delay_us, c->lane[1].st));
+            for (int i = 1; i < nl && c->lane_delay_us > 0; ++i) HD_TRY(launch_spin_us(c->lane_delay_us * i, c->lane[i].st));
         }
     }
-    int rc;
+    int rc = 0;
     if (nl == 1) {
         rc = lane_step(c, c->lane[0], &c->pool, kind, x, aux, v, x0_out, c->eps_buf, B, S);
     } else {
-        const size_t off = (size_t)b0 * S * S;
-        StepParams v1 = v;
-        v1.tile_off += (uint64_t)b0;
-        rc = lane_step(c, c->lane[0], &c->lane[0].pool, kind, x, aux, v, x0_out, c->eps_buf, b0, S);
-        if (rc == 0)
-            rc = lane_step(c, c->lane[1], &c->lane[1].pool, kind, x + off, aux ? aux + off : nullptr, v1, x0_out ? x0_out + off : nullptr,
-                           c->eps_buf + off, B - b0, S);
+        for (int i = 0; i < nl && rc == 0; ++i) {
+            const int b0 = lane_start(B, nl, i), bn = lane_start(B, nl, i + 1) - b0;
+            const size_t off = (size_t)b0 * S * S;
+            StepParams vi = v;
+            vi.tile_off += (uint64_t)b0;
+            rc = lane_step(c, c->lane[i], &c->lane[i].pool, kind, x + off, aux ? aux + off : nullptr, vi, x0_out ? x0_out + off : nullptr,
+                           c->eps_buf + off, bn, S);
+        }
     }
     if (!c->in_chain || rc != 0) { const int rj = lanes_join(c, user); if (rc == 0) rc = rj; }
     return rc;
@@ -1031,26 +1047,45 @@ int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, con
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
     if (!c || !x || !kin) return HD_EINVAL;
     hd_ddpm_coef kk, *k = &kk;
-    if (!read_prefixed(kin, offsetof(hd_ddpm_coef, eps_coef), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);   // (without eps_coef: an ancestral step)
+    if (!hd_read_prefixed(kin, offsetof(hd_ddpm_coef, eps_coef), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);   // (without eps_coef: an ancestral step)
     if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
     if ((c->arch.self_condition != 0) != (cond != nullptr)) return fail(c, HD_EINVAL, "cond must be given iff self_condition");
     StepParams v{};
     v.f[0] = k->time_value; v.f[1] = k->sqrt_recip_alphas_cumprod; v.f[2] = k->sqrt_recipm1_alphas_cumprod;
     v.f[3] = k->posterior_mean_coef1; v.f[4] = k->posterior_mean_coef2; v.f[5] = k->sigma; v.f[6] = k->eps_coef;
     v.step = step; v.seed = seed; v.tile_off = tile_offset;
-    return keep_err(c, run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream));
+    // this step's arithmetic (hd_ddpm_coef.arith): the host's precision schedule over the chain
+    const int saved = c->f16w2;
+    if (k->arith == HD_ARITH_F16W2 && c->precision == HD_PREC_BF16X3) c->f16w2 = 1;
+    else if (k->arith > HD_ARITH_F16W2) return fail(c, HD_EINVAL, "hd_ddpm_coef.arith: unknown value");
+    const int rc = run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream);
+    c->f16w2 = saved;
+    return keep_err(c, rc);
 }
 
 int hd_ddrm_step(hd_ctx* c, float* x, const float* y, const float* z, const hd_ddrm_coef* kin, float* x0_out, int B, int S,
                  uint64_t seed, uint64_t tile_offset, uint32_t step, void* stream) {
     if (!c || !x || !y || !kin) return HD_EINVAL;
     hd_ddrm_coef kk, *k = &kk;
-    if (!read_prefixed(kin, sizeof(hd_ddrm_coef), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);
+    if (!hd_read_prefixed(kin, offsetof(hd_ddrm_coef, skip_network), k)) return fail(c, HD_EINVAL, kCoefSizeMsg);   // (without skip_network: revision 3)
     if (!c->loaded) return fail(c, HD_ESTATE, "weights not loaded: call hd_load_weights first");
     StepParams v{};
     v.f[0] = k->time_value; v.f[1] = k->sqrt_at; v.f[2] = k->sqrt_1m_at; v.f[3] = k->sqrt_at_next; v.f[4] = k->sigma_next;
     v.f[5] = k->sigma_0; v.f[6] = k->etaA; v.f[7] = k->etaB; v.f[8] = k->etaC;
     v.step = step; v.seed = seed; v.tile_off = tile_offset;
+    if (k->skip_network) {
+        // The identity degradation's third case with etaB == 1 (src/functions/denoising.py:99-100): the next state is built from y and fresh
+        // noise alone.  The SAME update kernel runs on an all-zero eps -- its x0 term is multiplied by (1 - etaB) = 0 -- so the state equals
+        // the full step's bit for bit; only the network's launches are gone.
+        if (k->skip_network != 1 || !(k->etaB == 1.f) || !(k->sigma_next > k->sigma_0))
+            return fail(c, HD_EINVAL, "hd_ddrm_coef.skip_network: this step's update reads the network (it needs etaB == 1 and sigma_next > sigma_0)");
+        if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
+        hipStream_t user = (hipStream_t)stream;
+        if (c->in_chain) HD_TRY(keep_err(c, lanes_join(c, user)));
+        if (hipMemsetAsync(c->eps_buf, 0, (size_t)B * S * S * sizeof(float), user) != hipSuccess) return fail(c, HD_EHIP, "hipMemsetAsync failed");
+        return keep_err(c, launch_ddrm_update(x, c->eps_buf, y, z, v.f[1], v.f[2], v.f[3], v.f[4], v.f[5], v.f[6], v.f[7], v.f[8], x0_out, B, S, v.seed,
+                                              v.tile_off, v.step, nullptr, user));
+    }
     return keep_err(c, run_step(c, 1, x, y, z, v, x0_out, B, S, (hipStream_t)stream));
 }
 
@@ -1061,7 +1096,7 @@ int hd_set_graphs(hd_ctx* c, int enable) {
 }
 
 int hd_set_chains(hd_ctx* c, int n) {
-    if (!c || n < 0 || n > 2) return HD_EINVAL;
+    if (!c || n < 0 || n > hd_ctx::MAX_LANES) return HD_EINVAL;
     if (c->in_chain) return fail(c, HD_ESTATE, "hd_set_chains inside an hd_chain_begin / hd_chain_end bracket");
     c->chains = n == 0 ? -1 : n;
     if (c->resB > 0 && hd_reserve(c, c->resB, c->resS) != HD_OK) return HD_EHIP;      // the half-batch workspaces, if they are now needed
@@ -1128,10 +1163,11 @@ int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, 
 int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {
-    if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3)) return HD_EINVAL;
+    if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3 && mode != 2 /* HD_PRECISION_F16W2 */)) return HD_EINVAL;
     // a captured step holds the kernels of the arithmetic it was captured under: the graph cache is keyed by the mode (run_step), so a
     // sampler that switches back and forth (ddim_sample runs exact fp32) keeps both sets instead of re-capturing every time
-    c->precision = mode;
+    c->precision = mode == 2 ? HD_PREC_BF16X3 : mode;
+    c->f16w2 = mode == 2;
     return HD_OK;
 }
 
@@ -1257,6 +1293,12 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
         rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, 16, st);
         a.cw.wsplit = (unsigned short*)psplit; a.cw.ck = cw.ck; a.precision = HD_PREC_BF16X3;
     }
+    void* psplit16 = nullptr;
+    if ((mode & 512) && (mode & 32) && rc == 0) {          // two fp16 products per multiply (3x3 only; launch_conv falls back to x3 where it does not apply)
+        if (KH != 3 || unsh || Cin % 16 || hipMalloc(&psplit16, (size_t)9 * Cin * cw.CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) rc = HD_EINVAL;
+        if (rc == 0) rc = launch_split_conv(cw.w, (unsigned short*)psplit16, 9, Cin, cw.CoutPad, 16, st, 1);
+        a.cw.wsplit16 = (unsigned short*)psplit16; a.f16w2 = 1;
+    }
     void* pwino = nullptr;
     if ((mode & 256) && rc == 0) {             // Winograd image + switch: launch_conv takes the F(2x2,3x3) kernel where the shape allows it
         conv_set_winograd(1);
@@ -1268,7 +1310,7 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
     if (rc == 0) rc = launch_conv(a, st, nullptr);
     if (mode & 256) conv_set_winograd(-1);
     (void)hipStreamSynchronize(st);
-    (void)hipFree(pw); if (pst) (void)hipFree(pst); if (psplit) (void)hipFree(psplit); if (pwino) (void)hipFree(pwino);
+    (void)hipFree(pw); if (pst) (void)hipFree(pst); if (psplit) (void)hipFree(psplit); if (pwino) (void)hipFree(pwino); if (psplit16) (void)hipFree(psplit16);
     return rc;
 }
 

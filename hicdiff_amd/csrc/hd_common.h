@@ -1,5 +1,6 @@
 // Shared declarations of the gfx950 HiCDiff engine (internal; the public surface is include/hicdiff_hip.h).
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -18,6 +19,7 @@ struct Act {
 struct ConvW {
     float* w = nullptr;
     unsigned short* wsplit = nullptr;   // split-bf16 image [taps][Cin/16][CoutPad][16 hi | 16 lo] (fast path; always 16-channel k-steps)
+    unsigned short* wsplit16 = nullptr; // 3x3 only: the same layout with fp16 hi | lo of the exact weight (two-product arithmetic, conv_bf16x3_kernel.h AR = 2)
     unsigned short* wino = nullptr;     // 3x3 only: Winograd F(2x2,3x3) filter transform, split bf16, MFMA-fragment order (conv_winograd.hip)
     float* bias = nullptr;
     int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;   // ck: activation slice of the bf16x3 kernel (32 where the channel counts allow)
@@ -82,12 +84,30 @@ struct ConvArgs {
     GnFinArgs gn_fin;                 // with gn_part: also finalize in the kernel when it can (launch_conv reports whether it did)
     // split-K workspace (conv_splitk(a) * B*H*W*Cout floats) for the convolutions the planner splits; null: never split
     float* splitk_ws = nullptr;
+    int f16w2 = 0;                    // with precision == HD_PREC_BF16X3: 3x3 layers that carry cw.wsplit16 take two fp16 products per multiply
     int plain_bf16 = 0;               // with precision == HD_PREC_BF16X3: drop the two correction products where a plain-bf16 variant exists (training option)
     // N-tile rule override (0: the default): feature maps of at most this many pixels take 64-wide N tiles.  The training steps set 64
     // (64 tiles per step: the 8x8 maps' 128-wide tiles fill a quarter of the chip; 28.1 -> 26.0 ms per UNet step); a rule by map size only.
     int narrow_max_hw = 0;
     int precision = HD_PREC_F32;
 };
+
+// A size-prefixed struct of the ABI (include/hicdiff_hip.h) -> a zero-filled copy of this build's revision.  Exactly `struct_bytes` bytes of
+// the caller's memory are read; sizes this build does not know -- a struct from a binding without the prefix shows up here as the bit
+// pattern of its first float -- are refused, never read past.
+template <typename T>
+static inline bool hd_read_prefixed(const T* src, size_t oldest_bytes, T* dst) {
+    uint32_t n;
+    memcpy(&n, src, sizeof(n));
+    if (n < oldest_bytes || n > sizeof(T) || n % 4) return false;
+    memset(dst, 0, sizeof(T));
+    memcpy(dst, src, n);
+    return true;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (device, kernel): the attribute is per device, a second context on another card of
+// the same process needs it too.  false: the call failed.
+bool hd_raise_dynamic_lds(const void* kernel, int bytes);
 
 #define HD_CHECK_HIP(expr)                                                                 \
     do {                                                                                   \
@@ -115,7 +135,7 @@ int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials
 
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
                      int standardize, int unshuffle, hipStream_t st);
-int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st);
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16 = 0);
 size_t conv_winograd_weight_bytes(int Cin, int CoutPad);
 int launch_pack_winograd(const float* packed, unsigned short* dst, int Cin, int CoutPad, hipStream_t st);   // packed: fp32 [9][Cin][CoutPad]
 bool conv_uses_winograd(const ConvArgs& a);   // a.precision must be set

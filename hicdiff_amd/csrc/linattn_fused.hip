@@ -389,12 +389,8 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
     const dim3 grid((unsigned)(B * nsplit));
     static const bool old64 = getenv("HICDIFF_KV64_OLD") && atoi(getenv("HICDIFF_KV64_OLD")) != 0;      // A/B switch of the round-3 kernel
     if (C == 64 && !old64) {
-        static bool raised = false;
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_kv64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-                hd_set_error("linattn_kv64: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
-            }
-            raised = true;
+        if (!hd_raise_dynamic_lds(reinterpret_cast<const void*>(linattn_kv64_kernel), 80 * 1024)) {
+            hd_set_error("linattn_kv64: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
         }
         // chunks per workgroup: as many as leave about two rounds of workgroups on 256 CUs x 2 slots, at most 16 (by the map size and the
         // batch only in the grid shape -- the partials do not depend on how chunks are grouped)

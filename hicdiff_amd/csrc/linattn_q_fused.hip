@@ -217,12 +217,8 @@ int launch_pack_q(const float* wqkv, const float* g, int C, unsigned short* dst,
 int launch_linattn_q_fused(const float* x, const float* stats, const unsigned short* wq, const unsigned short* wfold, const float* bias,
                            const float* gout, float* out, int B, int HW, int C, hipStream_t st) {
     if (C != 64) { hd_set_error("linattn_q_fused: 64-channel maps only"); return -1; }
-    static bool raised = false;
-    if (!raised) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_q_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, QF_LDS) != hipSuccess) {
-            hd_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
-        }
-        raised = true;
+    if (!hd_raise_dynamic_lds(reinterpret_cast<const void*>(linattn_q_fused_kernel), QF_LDS)) {
+        hd_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
     }
     const int tiles = (HW + 255) / 256;
     hipLaunchKernelGGL(linattn_q_fused_kernel, dim3((unsigned)(B * tiles)), dim3(512), QF_LDS, st, x, stats, wq, wfold, bias, gout, out, HW, tiles);

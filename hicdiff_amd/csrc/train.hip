@@ -1103,16 +1103,18 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 }
 
 // ---- loss ---------------------------------------------------------------------------------------------------------
-// per[b] = mean_i f(out - eps); dout = f'(out - eps) / (B * n)   (l2: f = d^2; l1: f = |d|; p2 weight == 1)
+// per[b] = w_b mean_i f(out - eps); dout = w_b f'(out - eps) / (B * n)   (l2: f = d^2; l1: f = |d|; w_b = p2_loss_weight[t_b], src/hicdiff.py:746,
+// or 1 when lw == nullptr)
 // per[b] = per-sample loss, per[B + b] = sum of the sample's dout (the last convolution's bias gradient)
 // objective (src/hicdiff.py:733-741): 0 the target is the noise; 1 x_start itself; 2 v = a_t eps - s_t x_start (predict_v, :542-546)
 __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict__ out, const float* __restrict__ eps, int n, int B, int l2,
                                                         float* __restrict__ per, float* __restrict__ dout, int objective = 0,
                                                         const float* __restrict__ x0 = nullptr, const float* __restrict__ a_t = nullptr,
-                                                        const float* __restrict__ s_t = nullptr) {
+                                                        const float* __restrict__ s_t = nullptr, const float* __restrict__ lw = nullptr) {
     __shared__ float red[256], red2[256];
     const int b = blockIdx.x;
-    const float inv = 1.f / ((float)B * (float)n);
+    const float wb = lw ? lw[b] : 1.f;
+    const float inv = wb / ((float)B * (float)n);
     const float av = objective == 2 ? a_t[b] : 0.f, sv = objective == 2 ? s_t[b] : 0.f;
     float s = 0.f, sg = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(256) void loss_grad_kernel(const float* __restrict_
         if (threadIdx.x < m) { red[threadIdx.x] += red[threadIdx.x + m]; red2[threadIdx.x] += red2[threadIdx.x + m]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { per[b] = red[0] / (float)n; per[B + b] = red2[0]; }
+    if (threadIdx.x == 0) { per[b] = wb * (red[0] / (float)n); per[B + b] = red2[0]; }
 }
 __global__ void mean_kernel(const float* __restrict__ per, int B, float* __restrict__ loss, float* __restrict__ dbias) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -1374,6 +1376,7 @@ struct hd_trainer {
     float *temb_act = nullptr, *temb_actT = nullptr; int Bp = 0;      // act(temb) and its transpose ([tdim][Bp], Bp = B rounded up to 64): the FiLM projections' input
     void* fjobs_dev = nullptr; int fjobs_n = 0, ftiles = 0;    // hicedrn: the job table of prep_filters_kernel (every block's two packed images in one launch)
     int objective = 0;                    // hd_train_set_objective: what the network's output is compared with (0 noise, 1 x_start, 2 v)
+    const float* loss_w = nullptr;        // hd_train_set_loss_weights: per-sample weights of the next steps' loss (device, [B]); null: 1
     float* stage_snap = nullptr;          // tests: hd_debug_train_stage_snapshot
     const float* cur_grads = nullptr;     // the gradient buffer of the step being queued
     size_t o_head_w = 0, o_head_b = 0, o_t1w = 0, o_t1b = 0, o_t3w = 0, o_t3b = 0, o_bt_w = 0, o_bt_b = 0, o_tail_w = 0, o_tail_b = 0;
@@ -1602,6 +1605,13 @@ int hd_train_set_objective(hd_trainer* t, int objective) {
     return HD_OK;
 }
 
+int hd_train_set_loss_weights(hd_trainer* t, const float* w) {
+    if (!t) return HD_EINVAL;
+    if (w && t->arch.sr3) return tfail(t, HD_EINVAL, "the SR3 flavour's loss is a plain mean (src/hicdiff_sr3.py:786-791)");
+    t->loss_w = w;
+    return HD_OK;
+}
+
 int hd_train_stage_count(const hd_trainer* t) { return t ? (int)t->stage_ev.size() : HD_EINVAL; }
 
 int hd_train_slot_stage(const hd_trainer* t, int slot, int* stage) {
@@ -1750,7 +1760,7 @@ extern "C" int hd_train_loss_backward(hd_trainer* tr, const float* params, float
         o.precision = HD_PREC_BF16X3;
         TR_TRY(launch_conv(o, st, nullptr));
     }
-    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, st, tr->out, noise, HW, B, l2 ? 1 : 0, tr->per, tr->dout, tr->objective, x_start, a_t, s_t);
+    hipLaunchKernelGGL(loss_grad_kernel, dim3(B), dim3(256), 0, st, tr->out, noise, HW, B, l2 ? 1 : 0, tr->per, tr->dout, tr->objective, x_start, a_t, s_t, tr->loss_w);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, st, tr->per, B, loss, grads + tr->o_tail_b);
     TR_TRY(check_launch("loss"));
 

@@ -19,13 +19,20 @@ def compute_alpha(beta, t):
 
 
 def efficient_generalized_steps(x, seq, model, b, H_funcs, y_0, sigma_0, etaB, etaA, etaC, cls_fn=None, classes=None,
-                                device=None, noise=None, keep="all", seed=1234, tile_offset=0):
+                                device=None, noise=None, keep="all", seed=1234, tile_offset=0, skip_inert_steps=False):
     """Returns (xs, x0_preds) like the reference (lists over steps; ``keep='last'`` keeps only the
     final entries).  ``model`` is the epsilon-network module (``diffusion.model``, inference.py:109).
     ``noise``: None -> device Philox; or an object with ``randn(shape)`` replaying the reference's three
-    draws per step (:92 full, :96 selected pixels, :100 full)."""
+    draws per step (:92 full, :96 selected pixels, :100 full).
+    ``skip_inert_steps`` (identity degradation only, off by default): with etaB == 1, while sigma_next > sigma_0 every pixel takes the
+    update's third case, x_next = sqrt(a_next) (y + sqrt(sigma_next^2 - sigma_0^2) z) (:99-100) -- the network's output is multiplied by
+    (1 - etaB) = 0.  Such steps then run the update kernel alone (hd_ddrm_coef.skip_network): the states are bit-identical to the full
+    run's, but the x0 estimates of those steps do not exist, so ``keep='all'`` is refused.  With inference.py's defaults (50 of 1000
+    steps, sigma_0 = 0.1) 47 of the 50 network evaluations are inert."""
     if cls_fn is not None:
         raise NotImplementedError("classifier guidance is not used by HiCDiff")
+    if skip_inert_steps and (keep == "all" or not isinstance(H_funcs, Denoising)):
+        raise ValueError("skip_inert_steps needs the identity degradation and keep='last': the skipped steps produce no x0 estimate")
     if not isinstance(H_funcs, Denoising):
         return _general_steps(x, seq, model, b, H_funcs, y_0, sigma_0, etaB, etaA, etaC, noise, keep, seed, tile_offset)
     with torch.no_grad():
@@ -57,6 +64,7 @@ def efficient_generalized_steps(x, seq, model, b, H_funcs, y_0, sigma_0, etaB, e
                 sigma_next = (1 - at_next).sqrt() / at_next.sqrt()
                 co.sigma_next, co.sigma_0, co.etaA, co.etaB, co.etaC = float(sigma_next), float(sigma_0), float(etaA), float(etaB), float(etaC)
                 co.time_value = float(i)
+                co.skip_network = 1 if (skip_inert_steps and float(etaB) == 1.0 and co.sigma_next > co.sigma_0) else 0
                 z = None
                 if noise is not None:
                     after = bool(sigma_next < sigma_0)

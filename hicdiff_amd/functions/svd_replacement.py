@@ -58,14 +58,25 @@ def kvec_matmul(src, mat):
 
 
 def sandwich_matmul(A, x, Bm):
-    """A @ x[i] @ Bm for a stack x of S x S images (S <= 64): hd_sandwich_matmul."""
+    """A @ x[i] @ Bm for a stack x of S x S images: hd_sandwich_matmul (S <= 64: one workgroup per image with both factors in LDS); larger
+    images -- the reference's operators are written for any img_dim -- take two hd_dense_matmul calls, (x Bm) and then A (x Bm) through
+    its transpose."""
     S = A.shape[0]
     xs = x.contiguous().float()
+    Ac, Bc = A.contiguous().float(), Bm.contiguous().float()        # named: the copies of transposed views must outlive the launch
+    if Ac.device != xs.device or Bc.device != xs.device:
+        raise ValueError("sandwich_matmul: factors and images must live on the same device")
+    n = xs.numel() // (S * S)
+    if S > 64:
+        t = dense_matmul(xs.reshape(n * S, S), Bc)                                                  # x Bm
+        tt = t.reshape(n, S, S).transpose(1, 2).contiguous().reshape(n * S, S)                    # (x Bm)^T
+        r = dense_matmul(tt, Ac.t().contiguous())                                                    # (x Bm)^T A^T = (A x Bm)^T
+        return r.reshape(n, S, S).transpose(1, 2).contiguous().reshape(xs.shape)
     dst = torch.empty_like(xs)
-    rc = L.load().hd_sandwich_matmul(C.c_void_p(A.contiguous().data_ptr()), C.c_void_p(xs.data_ptr()), C.c_void_p(Bm.contiguous().data_ptr()),
-                                     C.c_void_p(dst.data_ptr()), xs.numel() // (S * S), S, _stream(xs.device))
+    rc = L.load().hd_sandwich_matmul(C.c_void_p(Ac.data_ptr()), C.c_void_p(xs.data_ptr()), C.c_void_p(Bc.data_ptr()),
+                                     C.c_void_p(dst.data_ptr()), n, S, _stream(xs.device))
     if rc != 0:
-        raise L.HdError(rc, "hd_sandwich_matmul failed (S <= 64)")
+        raise L.HdError(rc, "hd_sandwich_matmul failed")
     return dst
 
 

@@ -12,6 +12,7 @@ kernel_size = 3
 
 class hicedrn_Diff(EpsNetBase):
     _SR3 = False
+    EARLY_BAND_OK = True       # the samplers' precision schedule applies (hicdiff_amd/_diffusion.py:_early_band; profiles/r04_e_*)
     _native_train = True       # hd_train_* covers this network (unconditional and self_condition); see hicdiff_amd/_training.py
 
     def __init__(self, channels=1, out_dim=None, number_resnet=32, self_condition=False,

@@ -87,7 +87,8 @@ typedef struct {
 /* Coefficients of one ancestral reverse step, gathered by the host from the 13 schedule buffers of
  * GaussianDiffusion.__init__ (src/hicdiff.py:494-522) at index t. */
 typedef struct {
-    uint32_t struct_bytes;               /* = sizeof(hd_ddpm_coef) of the caller's header (32 in revision 3; 28 = a revision-3 struct without eps_coef is accepted) */
+    uint32_t struct_bytes;               /* = sizeof(hd_ddpm_coef) of the caller's header (36 with `arith`, round 4; 32 and 28 -- revision-3 structs without
+                                            `arith` / without `eps_coef` -- are accepted: the missing fields read as 0) */
     float sqrt_recip_alphas_cumprod;     /* predict_start_from_noise, src/hicdiff.py:529-533 */
     float sqrt_recipm1_alphas_cumprod;
     float posterior_mean_coef1;          /* q_posterior, src/hicdiff.py:553-560 */
@@ -96,17 +97,25 @@ typedef struct {
     float time_value;                    /* value fed to the time embedding: t, or the SR3 noise level */
     float eps_coef;                      /* weight of eps itself in the update; 0 for the ancestral step.  A DDIM step (src/hicdiff.py:622-664) is
                                             coef1 = sqrt(alpha_next), coef2 = 0, eps_coef = sqrt(1 - alpha_next - sigma^2), sigma = eta-term */
+    uint32_t arith;                      /* arithmetic of THIS step's 3x3 convolutions: HD_ARITH_DEFAULT (the context's, hd_set_precision) or
+                                            HD_ARITH_F16W2 (two fp16 products per multiply; only on a context in HD_PRECISION_BF16X3).  The host's
+                                            precision schedule over a chain: hicdiff_amd/_diffusion.py, DESIGN.md section 4e */
 } hd_ddpm_coef;
+enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1 };
 
 /* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
 typedef struct {
-    uint32_t struct_bytes;  /* = sizeof(hd_ddrm_coef) (40 in revision 3) */
+    uint32_t struct_bytes;  /* = sizeof(hd_ddrm_coef) (44 with `skip_network`, round 4; the 40 bytes of revision 3 are accepted) */
     float sqrt_at;          /* sqrt(alpha_bar_t) */
     float sqrt_1m_at;       /* sqrt(1 - alpha_bar_t) */
     float sqrt_at_next;     /* sqrt(alpha_bar_next) */
     float sigma_next;       /* sqrt(1 - a_next) / sqrt(a_next) */
     float sigma_0, etaA, etaB, etaC;
     float time_value;       /* t as float */
+    uint32_t skip_network;  /* 1: do not evaluate the epsilon-network -- allowed only on a step whose update provably ignores it: etaB == 1 and
+                               sigma_next > sigma_0, where every pixel takes the third case and x_next = sqrt(a_next) (y + sqrt(sigma_next^2 -
+                               sigma_0^2) z), src/functions/denoising.py:99-100.  Any other step is refused with HD_EINVAL.  x_next is
+                               bit-identical to the full step's; x0_out (the network's x0 estimate) is NOT produced on such a step. */
 } hd_ddrm_coef;
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
@@ -134,8 +143,12 @@ int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
  *   HD_PRECISION_BF16X3  default: operands split into two bf16 (x = hi + lo), three bf16 MFMAs per product
  *                        with fp32 accumulation -- ~2e-5 relative error per forward, inside the 1e-3
  *                        parity bound, at up to 5x the fp32 MFMA rate.
+ *   HD_PRECISION_F16W2   BF16X3 with the 3x3 convolutions on TWO fp16 products per multiply, xh (wh + wl): the activation rounded
+ *                        once to fp16, the weight exact -- ~1e-3 per forward, i.e. NOT inside the parity bound as a whole-chain mode;
+ *                        it exists for the early half of a long ancestral chain, where the chain damps the error (the per-step
+ *                        switch hd_ddpm_coef.arith is what the samplers use), and as a context-wide mode for tests and measurements.
  * The environment variable HICDIFF_PRECISION=f32|bf16x3 sets the default at hd_create. */
-enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1 };
+enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1, HD_PRECISION_F16W2 = 2 };
 int hd_set_precision(hd_ctx* ctx, int mode);
 
 /* ---- DDRM with a general degradation H = U S V^T (src/functions/denoising.py:11-111 over the operators of
@@ -178,13 +191,13 @@ int hd_set_graphs(hd_ctx* ctx, int enable);
  * caller must not touch x / cond / y / x0_out on its stream inside the bracket.  A step that has to run on the caller's stream
  * (replayed noise, a batch too small to replay) joins first, so mixing stays correct, only slower.  Large steps are cut into two
  * half-batch chains (tiles are independent for the whole chain) that advance side by side on two streams of the
- * context and only meet at hd_chain_end -- results are bit-identical to the single chain.  hd_set_chains: 2 always cuts, 1 never,
- * 0 restores the default (from 512 k pixels per step on); env HICDIFF_CHAINS=1|2 sets it at hd_create.  hd_reserve / hd_set_chains
- * inside a bracket return HD_ESTATE. */
+ * context and only meet at hd_chain_end -- results are bit-identical to the single chain.  hd_set_chains(n): n = 1 never cuts,
+ * n = 2..4 always cuts into n sub-batches, 0 restores the default (two from 512 k pixels per step on); env HICDIFF_CHAINS=n sets it at
+ * hd_create.  hd_reserve / hd_set_chains inside a bracket return HD_ESTATE. */
 int hd_chain_begin(hd_ctx* ctx, void* stream);
 int hd_chain_end(hd_ctx* ctx, void* stream);
 int hd_set_chains(hd_ctx* ctx, int n);
-int hd_chains_for(const hd_ctx* ctx, int B, int S);   /* how many chains a replayed step of B tiles of S x S is cut into: 1 or 2 */
+int hd_chains_for(const hd_ctx* ctx, int B, int S);   /* how many chains a replayed step of B tiles of S x S is cut into (1..4) */
 
 /* ---- the hot path -------------------------------------------------------------------------- */
 
@@ -290,6 +303,9 @@ int hd_train_set_precision(hd_trainer* t, int mode);
 /* What the network's output is compared with (GaussianDiffusion(objective = ...), src/hicdiff.py:441,733-741): 0 the noise (default; the
  * only one a reference driver uses), 1 x_start, 2 v = a_t noise - s_t x_start (predict_v, :542-546).  Not for SR3 nets. */
 int hd_train_set_objective(hd_trainer* t, int objective);
+/* Per-sample loss weights of the following hd_train_loss_backward calls: w[b] = p2_loss_weight[t_b] (src/hicdiff.py:522,746; device
+ * pointer to B floats the caller keeps alive, or NULL for weights of 1 -- the reference's own setting, p2_loss_weight_gamma = 0). */
+int hd_train_set_loss_weights(hd_trainer* t, const float* w);
 
 /* Number of parameter tensors; *total_floats = length of the flat arrays. */
 int hd_train_param_count(const hd_trainer* t, long long* total_floats);

@@ -58,6 +58,9 @@ def create_parser():
     p.add_argument("--outdir", default=os.path.join(ROOT, "Outputs_diff"))
     p.add_argument("--seed", type=int, default=1234)
     p.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3")
+    p.add_argument("--skip-inert-steps", action="store_true",
+                   help="DDRM denoising: do not evaluate the network on the steps whose update ignores it (etaB = 1 while sigma_next > sigma_0: with the "
+                        "defaults 47 of 50 steps); the tiles are bit-identical, only faster.  Off by default: the reference evaluates every step")
     p.add_argument("--metrics", action="store_true", help="report mse / psnr / ssim / snr / pcc of predict vs target (GPU, stard_metrics.py:146-160)")
     return p
 
@@ -118,6 +121,23 @@ def run_test_split(args, conditional, device):
     return torch.from_numpy(predict)
 
 
+def _store_barrier(dist, rank, world, key="hicdiff_eval_done", poll_s=5.0):
+    """Rank 0 posts a key on the rendezvous store when it is done, the others poll for it: no collective is in flight while they wait, so no
+    collective watchdog can fire however long rank 0 takes."""
+    import time
+    store = dist.distributed_c10d._get_default_store()
+    if rank == 0:
+        store.set(key, "1")
+        return
+    while True:
+        try:
+            if store.check([key]):
+                return
+        except RuntimeError:
+            return                      # the store went away with rank 0: nothing left to wait for
+        time.sleep(poll_s)
+
+
 def main(argv=None):
     args = create_parser().parse_args(argv)
     conditional = args.conditional or not args.unspervised
@@ -135,10 +155,16 @@ def main(argv=None):
         # The evaluation harness (VisionMetrics.getMetrics, upstream a single-process flow) prepares the Splits/ files and writes one set of
         # Outputs_diff/<name>/*.npy: under torchrun it runs on rank 0 only -- every rank running it would race on those files -- and the other
         # ranks wait at the common barrier.  (Sharded sampling of a tile list is the path below: --noisy / --matrix / --synthetic.)
-        predict = run_test_split(args, conditional, device) if rank == 0 else None
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
+        # The wait is a store barrier with a long timeout, reached in a `finally`: an NCCL barrier would abort the job after its watchdog's
+        # ten minutes while rank 0 is still sampling a whole test split, and a rank 0 that raises must not leave the others hanging.
+        predict = None
+        try:
+            predict = run_test_split(args, conditional, device) if rank == 0 else None
+        finally:
+            if dist is not None:
+                import datetime
+                dist.monitored_barrier(timeout=datetime.timedelta(hours=24)) if dist.get_backend() == "gloo" else _store_barrier(dist, rank, world)
+                dist.destroy_process_group()
         return predict
     origins = None
     if args.matrix:
@@ -177,7 +203,7 @@ def main(argv=None):
                 x = diffusion.model.engine(device).randn(b1 - b0, S, args.seed, b0, 1 << 20)
                 xs, _ = efficient_generalized_steps(x, seq, diffusion.model, betas, MakeFunc("deno", 1, S, device), y.reshape(b1 - b0, -1),
                                                     args.sigma if args.sigma <= 1 else 0.1, etaB=1.0, etaA=0.85, etaC=0.85,
-                                                    keep="last", seed=args.seed, tile_offset=b0)
+                                                    keep="last", seed=args.seed, tile_offset=b0, skip_inert_steps=args.skip_inert_steps)
                 outs.append(xs[-1])
         return torch.cat(outs) if outs else torch.empty((0, 1, S, S), device=device)
 

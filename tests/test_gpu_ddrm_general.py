@@ -79,8 +79,11 @@ def test_general_h_dense_factors_and_matmul_primitives():
     assert rel_err(a.double() @ b.double(), SV.dense_matmul(a.cuda(), b.cuda()).cpu().double()) < 1e-6
     A, Bm, X = torch.randn(40, 40, generator=gen), torch.randn(40, 40, generator=gen), torch.randn(5, 40, 40, generator=gen)
     assert rel_err(A.double() @ X.double() @ Bm.double(), SV.sandwich_matmul(A.cuda(), X.cuda(), Bm.cuda()).cpu().double()) < 1e-6
-    with pytest.raises(Exception):
-        SV.sandwich_matmul(torch.randn(65, 65).cuda(), torch.randn(1, 65, 65).cuda(), torch.randn(65, 65).cuda())     # S <= 64
+    # images wider than the LDS form takes (S > 64: the reference's operators are written for any img_dim) go through two dense products
+    A, Bm, X = torch.randn(96, 96, generator=gen), torch.randn(96, 96, generator=gen), torch.randn(3, 96, 96, generator=gen)
+    assert rel_err(A.double() @ X.double() @ Bm.double(), SV.sandwich_matmul(A.cuda(), X.cuda(), Bm.cuda().t().contiguous().t()).cpu().double()) < 1e-6
+    with pytest.raises(ValueError):
+        SV.sandwich_matmul(A, X.cuda(), Bm.cuda())                     # a factor left on the host
 
 
 def test_makefunc_builds_every_degradation_and_refuses_unknown_names():

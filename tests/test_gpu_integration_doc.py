@@ -32,7 +32,7 @@ def test_level2_block_matches_the_binding():
     ns = {"C": C}
     for m in re.finditer(r"^class (\w+)\(C\.Structure\):.*?(?=^\S)", src, re.S | re.M):
         exec(m.group(0), ns)
-    assert C.sizeof(ns["Coef"]) == C.sizeof(L.HdDdpmCoef) == 32
+    assert C.sizeof(ns["Coef"]) == C.sizeof(L.HdDdpmCoef) == 36
     assert [f[0] for f in ns["Coef"]._fields_] == [f[0] for f in L.HdDdpmCoef._fields_]
     assert C.sizeof(ns["Arch"]) == C.sizeof(L.HdArchDesc)
     assert C.sizeof(ns["Named"]) == C.sizeof(L.HdNamedTensor)

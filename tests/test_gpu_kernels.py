@@ -473,3 +473,44 @@ def test_winograd_routes_whole_networks_within_the_parity_bound():
         assert rel_err(g["hicedrn_cond_n3_s64_eps"], out) < 1e-4
     finally:
         lib.hd_debug_winograd(-1)
+
+
+# ---------------------------------------------------------------- two fp16 products per multiply: xh (wh + wl)
+
+F16W2_TOL = 2e-3      # the activation is rounded once to fp16 (2^-12 relative per operand); the weight is exact to 2^-22
+
+
+@pytest.mark.parametrize("ck", [32, 96], ids=["ck16", "ck32"])
+@pytest.mark.parametrize("B,S,Cin,Cout", [(2, 16, 64, 64), (1, 64, 64, 64), (3, 8, 128, 256), (2, 40, 64, 128), (1, 32, 128, 256), (2, 64, 128, 64)])
+def test_conv3x3_two_fp16_products(B, S, Cin, Cout, ck):
+    """The 3x3 kernels' second arithmetic (conv_bf16x3_kernel.h AR = 2) over the tile variants the networks use, against torch CPU conv2d
+    AND against the same convolution of the fp16-rounded activations with exact weights -- the arithmetic the mode is defined as -- at the
+    split kernels' own bound."""
+    x, w, b = rnd(1, B, Cin, S, S), rnd(2, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(3, Cout)
+    got = run_conv(x, None, w, b, 3, 512 | ck)
+    assert rel_err(F.conv2d(x, w, b, padding=1), got) < F16W2_TOL
+    assert rel_err(F.conv2d(x.half().float(), w, b, padding=1), got) < 1e-4
+    assert torch.equal(got, run_conv(x, None, w, b, 3, 512 | ck))
+
+
+def test_conv3x3_two_fp16_products_loaders_and_geometry():
+    """GroupNorm-apply + SiLU loader (rounding happens AFTER the transform), concat of two sources, nearest-x2 upsample."""
+    B, Cc, S = 3, 64, 32
+    x, w, b = rnd(1, B, Cc, S, S), rnd(2, 64, Cc, 3, 3) / 24, rnd(3, 64)
+    A, Bv = rnd(4, B, Cc) * 0.5 + 1, rnd(5, B, Cc)
+    t = F.silu(x * A[:, :, None, None] + Bv[:, :, None, None])
+    got = run_conv(x, None, w, b, 3, 8 | 512 | 96, A=A, Bv=Bv)
+    assert rel_err(F.conv2d(t.half().float(), w, b, padding=1), got) < 1e-4
+    x0, x1 = rnd(6, 2, 64, 40, 40), rnd(7, 2, 64, 40, 40)
+    w2 = rnd(8, 64, 128, 3, 3) / 34
+    got = run_conv(x0, x1, w2, b, 3, 512 | 96)
+    assert rel_err(F.conv2d(torch.cat((x0, x1), 1).half().float(), w2, b, padding=1), got) < 1e-4
+    xs = rnd(9, 2, 128, 16, 16)
+    got = run_conv(xs, None, w2, b, 3, 1 | 512 | 96, out_hw=(32, 32))
+    assert rel_err(F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest").half().float(), w2, b, padding=1), got) < 1e-4
+
+
+def test_conv1x1_ignores_the_two_product_switch():
+    """Only the 3x3 kernels have the second arithmetic: a 1x1 layer asked for it runs split-bf16 x3 (bit-identical)."""
+    x, w, b = rnd(1, 2, 64, 16, 16), rnd(2, 64, 64, 1, 1) / 8, rnd(3, 64)
+    assert torch.equal(run_conv(x, None, w, b, 1, 96), run_conv(x, None, w, b, 1, 96))

@@ -179,6 +179,51 @@ def test_graph_replayed_ddrm_chain_vs_oracle(net_kind, sigma_0, precision):
     assert torch.equal(xs2[-1], xs[-1])
 
 
+@pytest.mark.parametrize("net_kind", ["unet", "hicedrn3"])
+@pytest.mark.parametrize("sigma_0", [0.1, 1.0])
+def test_ddrm_skip_inert_steps_is_bit_identical(net_kind, sigma_0):
+    """--skip-inert-steps (opt-in): with etaB = 1, while sigma_next > sigma_0 the update is y + sqrt(sigma_next^2 - sigma_0^2) z whatever the
+    network says (src/functions/denoising.py:99-100); those steps run the update kernel alone.  The final tiles and the final x0 estimate
+    equal the full run's bit for bit, with device noise and with replayed noise; 47 (sigma_0 = 0.1) / 36 (1.0) of the 50 steps are skipped."""
+    from hicdiff_amd import _lib as L
+    from hicdiff_amd.functions.H_func import MakeFunc
+    from hicdiff_amd.functions.denoising import efficient_generalized_steps
+    from oracle import ddrm as ODD
+    B, S, seed = 2, 40, 31337
+    m = product_unet("uncond") if net_kind == "unet" else product_hicedrn("uncond", 3)
+    betas = ODD.ddrm_betas("linear", 1000).cuda()
+    hq = tiles(5, B, S)
+    y0 = (hq + sigma_0 * torch.randn(hq.shape, generator=torch.Generator().manual_seed(6))).clamp(-1, 1).cuda()
+    x = device_randn(B, S, seed, 0, 1000)
+    H = MakeFunc("deno", 1, S, device="cuda")
+    seq = range(0, 1000, 20)
+    ab = (1 - torch.cat([torch.zeros(1), betas.cpu()])).cumprod(0)
+    inert = sum(1 for j in [-1] + list(seq)[:-1] if float(((1 - ab[j + 1]) / ab[j + 1]).sqrt()) > sigma_0)
+    assert inert == (47 if sigma_0 == 0.1 else 36)
+
+    def run(skip, noise=None):
+        xs, x0s = efficient_generalized_steps(x.clone(), seq, m, betas, H, y0, sigma_0, etaB=1.0, etaA=0.85, etaC=0.85, noise=noise, seed=seed,
+                                              keep="last", skip_inert_steps=skip)
+        return xs[-1].clone(), x0s[-1].clone()
+
+    full, full0 = run(False)
+    fast, fast0 = run(True)
+    assert torch.equal(full, fast) and torch.equal(full0, fast0)
+    from hicdiff_amd.hicdiff import HostReplayNoise
+    full, full0 = run(False, HostReplayNoise(3, "cuda"))
+    fast, fast0 = run(True, HostReplayNoise(3, "cuda"))
+    assert torch.equal(full, fast) and torch.equal(full0, fast0)
+    with pytest.raises(ValueError):
+        efficient_generalized_steps(x.clone(), seq, m, betas, H, y0, sigma_0, etaB=1.0, etaA=0.85, etaC=0.85, keep="all", skip_inert_steps=True)
+    # the library refuses the switch on a step whose update reads the network
+    eng = _eng(m)
+    co = L.HdDdrmCoef()
+    co.sqrt_at, co.sqrt_1m_at, co.sqrt_at_next, co.sigma_next, co.sigma_0 = 0.8, 0.6, 0.85, 0.62, 1.0      # sigma_next < sigma_0
+    co.etaA, co.etaB, co.etaC, co.time_value, co.skip_network = 0.85, 1.0, 0.85, 300.0, 1
+    with pytest.raises(L.HdError):
+        eng.ddrm_step(x.clone(), y0, None, co, None, seed=1, tile_offset=0, step=0)
+
+
 @pytest.mark.parametrize("eta", [0.0, 0.5])
 def test_graph_replayed_ddim_vs_oracle(eta):
     """DDIM (src/hicdiff.py:622-664) on the fused step: 20 of 1000 steps with device noise, graph replay, against the oracle over the
@@ -269,6 +314,9 @@ def test_two_half_batch_chains_equal_the_single_chain(kind, precision):
     two = run()
     assert torch.equal(one, two)
     assert torch.equal(two, run())                      # and repeats
+    eng.set_chains(3)                                   # 2 + 2 + 2
+    assert eng.chains_for(B, S) == 3
+    assert torch.equal(one, run())
     # the per-step form without a bracket (p_sample: fork and join around every step) goes through the same lanes
     x = torch.randn(B, 1, S, S, generator=torch.Generator().manual_seed(1)).cuda()
     cond = lq if kind != "uncond" else None
@@ -340,7 +388,7 @@ def test_chain_bracket_state_errors():
     assert eng.lib.hd_set_chains(eng.ctx, 2) == L.HD_ESTATE
     assert b"bracket" in eng.lib.hd_last_error(eng.ctx)
     assert eng.lib.hd_chain_end(eng.ctx, st) == 0
-    assert eng.lib.hd_set_chains(eng.ctx, 3) == L.HD_EINVAL
+    assert eng.lib.hd_set_chains(eng.ctx, 5) == L.HD_EINVAL
 
 
 @pytest.mark.parametrize("kind", ["uncond", "cond"])
@@ -521,6 +569,69 @@ def test_full_length_chain_drift_vs_oracle(precision, capsys):
         print(f"\n[drift {precision}] " + " ".join(f"t={t}:{e:.2e}" for t, e in drift.items()))
     assert rel_err(want, stack[:, T]) < CHAIN_TOL
     assert max(drift.values()) < CHAIN_TOL
+
+
+def test_early_band_schedule_is_what_the_long_chain_runs_and_nothing_else():
+    """The precision schedule (hicdiff_amd/_diffusion.py:_early_band): two fp16 products in the 3x3 convolutions for t >= T / 2 of chains of
+    at least 500 steps; 50-step chains, the second half, a network that opts out and a switched-off schedule keep three products."""
+    from hicdiff_amd import _lib as L
+    d = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
+    assert [d._coef(t).arith for t in (999, 500, 499, 0)] == [L.HD_ARITH_F16W2, L.HD_ARITH_F16W2, L.HD_ARITH_DEFAULT, L.HD_ARITH_DEFAULT]
+    d.early_band_f16 = False
+    assert d._coef(999).arith == L.HD_ARITH_DEFAULT
+    d50 = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=50, loss_type="l2", beta_schedule="linear").cuda()
+    assert d50._coef(49).arith == L.HD_ARITH_DEFAULT
+    dh = diffusion_class("uncond")(product_hicedrn("uncond", 2), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
+    assert dh._coef(999).arith == L.HD_ARITH_F16W2 and dh._coef(499).arith == L.HD_ARITH_DEFAULT
+    dh.model.EARLY_BAND_OK = False                      # a network opts out by its class attribute
+    assert dh._coef(999).arith == L.HD_ARITH_DEFAULT
+    # one step each way on the same state: the early-band step differs from the three-product step (the switch is live) within its own bound
+    x = device_randn(4, 16, 1, 0, 1000)
+    d.early_band_f16 = True
+    a, _ = d.p_sample(x, 900)
+    d.early_band_f16 = False
+    b, _ = d.p_sample(x, 900)
+    assert not torch.equal(a, b) and rel_err(b, a) < 1e-3
+
+
+@pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
+def test_two_product_forward_vs_oracle(kind):
+    """HD_PRECISION_F16W2 as a context-wide mode (tests and measurements): a full-size UNet forward at 64x64 within the arithmetic's own
+    per-forward error of the fp32 oracle (CPU study: 1.1e-3 with every wide convolution rerouted; here the 3x3 ones only)."""
+    from hicdiff_amd import _lib as L
+    m, ref = product_unet(kind), oracle_unet(kind)
+    eng = _eng(m)
+    x, t = tiles(41, 2, 64), torch.tensor([700, 30])
+    cond = tiles(42, 2, 64) if kind != "uncond" else None
+    if kind == "sr3":
+        t = torch.tensor([[0.3], [0.9]])
+    want = oracle_once(("f16w2", kind), lambda: ref(x, t, cond))
+    base = m(x.cuda(), t.cuda(), None if cond is None else cond.cuda())
+    eng.set_precision(L.HD_PRECISION_F16W2)
+    got = m(x.cuda(), t.cuda(), None if cond is None else cond.cuda())
+    eng.set_precision(L.HD_PRECISION_BF16X3)
+    assert rel_err(want, base) < 1e-4
+    assert 1e-5 < rel_err(want, got) < 3e-3
+
+
+def test_full_length_hicedrn_chain_drift_vs_oracle(capsys):
+    """hicedrn (8 of its 32 blocks keep the CPU oracle to two minutes), 2 tiles of 40x40, T = 1000: the default path -- device noise, graph
+    replay, the precision schedule's early band on the 256 -> 256 body convolutions -- against the oracle over the same noise."""
+    B, S, T, seed = 2, 40, 1000, 404
+    net = product_hicedrn("uncond", 8)
+    d = diffusion_class("uncond")(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+    d.seed = seed
+    assert d._early_band(T - 1) and not d._early_band(0)
+    got = d.sample(torch.zeros(B, 1, S, S))
+    from oracle import diffusion as OD
+    ref = OD.DiffusionRef(oracle_hicedrn("uncond", 8), image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2")
+    want = ref.p_sample_loop((B, 1, S, S), AncestralDeviceNoise(B, S, T, seed))
+    err = rel_err(want, got)
+    d.early_band_f16 = False
+    err_x3 = rel_err(want, d.sample(torch.zeros(B, 1, S, S)))
+    with capsys.disabled():
+        print(f"\n[drift hicedrn8] early band {err:.2e}, split-bf16 x3 at every step {err_x3:.2e}")
+    assert err < CHAIN_TOL and err_x3 < CHAIN_TOL
 
 
 # ---------------------------------------------------------------- bench.py --gpus N as the driver runs it

@@ -12,6 +12,46 @@ from _util import golden, product_hicedrn, rel_err, tiles
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("net,loss", [("hicedrn", "l2"), ("unet", "l1")])
+def test_train_p2_loss_weight_vs_autograd_oracle(net, loss):
+    """GaussianDiffusion(p2_loss_weight_gamma != 0) (src/hicdiff.py:443,522,746; unused by the reference's drivers, but a constructor argument
+    of the kept API): the per-sample weights reach the native step's loss gradient (hd_train_set_loss_weights).  Loss and every gradient
+    against torch autograd over the oracle net with the same weights; gamma = 0 afterwards restores the plain mean."""
+    from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
+    from hicdiff_amd.hicdiff import GaussianDiffusion
+    B, S, gamma, k = 4, 16, 1.0, 1.0
+    if net == "hicedrn":
+        m = product_hicedrn("uncond", 2)
+        sd, cfg = _oracle_sd("uncond", 2)
+    else:
+        from _util import product_unet
+        m = product_unet("uncond", dim=64, mults=(1, 2))
+        cfg = ON.UnetCfg(dim=64, dim_mults=(1, 2), self_condition=False, sr3=False)
+        sd = W.fill_state_dict(W.unet_shapes(dim=64, dim_mults=(1, 2), self_condition=False, sr3=False))
+    d = GaussianDiffusion(m, image_size=S, timesteps=1000, loss_type=loss, beta_schedule="sigmoid", p2_loss_weight_gamma=gamma, p2_loss_weight_k=k).cuda()
+    d.train()
+    x0 = tiles(51, B, S)
+    gen = torch.Generator().manual_seed(9)
+    t, eps = torch.tensor([3, 250, 600, 990]), torch.randn(x0.shape, generator=gen)
+    buf = OD.diffusion_buffers("sigmoid", 1000, p2_gamma=gamma, p2_k=k)
+    assert torch.equal(buf["p2_loss_weight"], d.p2_loss_weight.cpu()) and float(buf["p2_loss_weight"].min()) < 0.1
+    ol, og = OTR.loss_and_grads(sd, cfg, buf, x0, t, eps, None, loss)
+    ol1, _ = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("sigmoid", 1000), x0, t, eps, None, loss)
+    assert abs(float(ol) - float(ol1)) > 0.05 * float(ol1)              # (the weights really change the loss)
+    val = d.p_losses(x0.cuda(), t.cuda(), eps.cuda())
+    val.backward()
+    assert abs(float(val.detach()) - float(ol)) <= 1e-4 * float(ol)
+    bad = {kk: rel_err(og[kk], p.grad) for kk, p in d.model.named_parameters() if not rel_err(og[kk], p.grad) <= 1e-3}
+    assert not bad, bad
+    # the same network under a diffusion object without weights: the trainer goes back to the plain mean
+    d1 = GaussianDiffusion(m, image_size=S, timesteps=1000, loss_type=loss, beta_schedule="sigmoid").cuda()
+    d1.train()
+    for p in m.parameters():
+        p.grad = None
+    v1 = d1.p_losses(x0.cuda(), t.cuda(), eps.cuda())
+    assert abs(float(v1.detach()) - float(ol1)) <= 1e-4 * float(ol1)
+
+
 def _diffusion(kind, nres, S, loss="l2", schedule="linear"):
     m = product_hicedrn(kind, nres)
     if kind == "cond":

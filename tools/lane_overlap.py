@@ -45,7 +45,7 @@ def main():
     a, b = busy[0], busy[1]
     t0 = max(by_q[a][0][0], by_q[b][0][0])
     t1 = min(by_q[a][-1][1], by_q[b][-1][1])
-    is33 = lambda n: "conv_igemm_bf16x3_kernel" in n and n.rstrip().endswith(", 9>")
+    is33 = lambda n: "conv_igemm_bf16x3_kernel" in n and ", 9>(" in n
     ev = []
     for q in (a, b):
         for s, e, n in by_q[q]:
