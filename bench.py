@@ -11,12 +11,15 @@
     python bench.py --gpus N --workload hicedrn64 --total-tiles 256      (strong-scaling form of BASELINE configs[3]: 256/N tiles per GPU)
 
 A "step" is one pass of the hot path over one batch: the epsilon-network forward plus the fused
-posterior update for B tiles (one hd_ddpm_step call).  All steps of a chain cost the same, so
-tiles/s for a full chain = tiles per batch / (1000 * seconds per step).  Because the chip lowers its
-clock under sustained MFMA load, the line also carries `sustained`: a whole 1000-step chain (or as much
-of one as fits the time budget) timed after the K-step region, next to the K-step figure.  Tiles shard across ranks
-with no data-path collective (weak scaling: B tiles per GPU); the one RCCL all-gather of the
-finished tiles is exercised after the timed region and reported separately.
+posterior update for B tiles (one hd_ddpm_step call).  Since round 4 a step's cost depends on the half of the
+chain it sits in (the precision schedule: two fp16 products in the 3x3 convolutions for t >= T/2, DESIGN.md
+section 4e), so the K timed steps are spread evenly over the chain (t = 999, 999 - 1000/K, ...): a stratified
+sample whose mean is the chain's mean for even K; tiles/s = tiles per batch / (1000 * mean seconds per step).
+The line also carries `sustained`: a whole 1000-step chain (or as much of one as fits the time budget) timed
+after the K-step region.  Tiles shard across ranks with no data-path collective (weak scaling: B tiles per
+GPU); the one RCCL all-gather of the finished tiles is exercised after the timed region and reported
+separately.  On each GPU the batch runs as two half-batch chains on two streams (hd_chain_begin / _end,
+DESIGN.md section 7b; `--chains 1` for one).
 
 Inputs are synthetic and already resident in HBM when the timed region starts: x_T from the
 device Philox generator, random-init weights of the named architecture (seeded).
@@ -47,7 +50,7 @@ PEAK_HBM_GBS = 8000.0
 T_CHAIN = 1000
 # HBM bytes per launch of each kernel from the FETCH_SIZE / WRITE_SIZE passes of this round (separate rocprofv3
 # --pmc runs of this script; profiles/README.md): a recorded measurement, reported as roofline.traffic with its source.
-TRAFFIC_FILE = {"unet64": os.path.join(ROOT, "profiles", "r03_n_unet64_b256_hbm_traffic.json")}
+TRAFFIC_FILE = {"unet64": os.path.join(ROOT, "profiles", "r04_k_unet64_b256_hbm_traffic.json")}
 
 
 def recorded_traffic(workload, kernel, batch, default_batch):
@@ -407,7 +410,7 @@ def main():
         return [T_CHAIN - 1 - (i * T_CHAIN) // n for i in range(n)]
 
     # set-up, not warm-up: the step's hipGraphs are captured on the second call of each arithmetic (engine.hip lane_step)
-    for t in (T_CHAIN - 1, 0):
+    for t in (T_CHAIN - 1, (T_CHAIN * 5) // 8, 0):
         run_ts([t, t, t])
     timed = consecutive(T_CHAIN, T_CHAIN - 1) if args.steps >= T_CHAIN else spread(args.steps)
     run_ts(spread(args.warmup))
@@ -477,24 +480,26 @@ def main():
         # A kernel's roofline follows its arithmetic: three bf16 MFMAs per product (2500 / 3), two fp16 MFMAs (2500 / 2: the early band's 3x3
         # kernels), or the exact-fp32 MFMA.
         def peak_of(name):
-            return PEAK_BF16_MFMA_TFLOPS / 2.0 if b"f16w2" in name else PEAK_BF16_MFMA_TFLOPS / 3.0 if b"bf16x3" in name else PEAK_F32_MFMA_TFLOPS
+            return (PEAK_BF16_MFMA_TFLOPS if b"f16w1" in name else PEAK_BF16_MFMA_TFLOPS / 2.0 if b"f16w2" in name else
+                    PEAK_BF16_MFMA_TFLOPS / 3.0 if b"bf16x3" in name else PEAK_F32_MFMA_TFLOPS)
 
         dom = max(rows, key=lambda r: r.total_ms)
         ach = dom.flops / (dom.total_ms * 1e-3) / 1e12 if dom.total_ms > 0 else 0.0
-        split = b"bf16x3" in dom.kernel or b"f16w2" in dom.kernel
+        split = b"bf16x3" in dom.kernel or b"f16w" in dom.kernel
         peak = peak_of(dom.kernel)
         traffic, traffic_src = recorded_traffic(args.workload, dom.kernel.decode(), B, WORK[args.workload]["B"])
         whole_flops = w["flop"] * B / sec_per_step / 1e12
         # the step's own MFMA roofline: the chain's mix of the two arithmetics over the timed steps (1x1 convolutions always take three products;
         # priced with the 3x3 layers, i.e. slightly in the step's favour -- they are 5 % of the flops)
-        step_peak = (early * PEAK_BF16_MFMA_TFLOPS / 2.0 + (len(timed) - early) * PEAK_BF16_MFMA_TFLOPS / 3.0) / len(timed) if split else PEAK_F32_MFMA_TFLOPS
+        per_product = [1.0 if (diff._early_band(t) and t >= int(diff.early_band_x1_from * T_CHAIN)) else 2.0 if diff._early_band(t) else 3.0 for t in timed]
+        step_peak = sum(PEAK_BF16_MFMA_TFLOPS / p for p in per_product) / len(timed) if split else PEAK_F32_MFMA_TFLOPS
         conv_ms = sum(r.total_ms for r in rows)
         roofline = {
             "bound": "mfma", "achieved": round(ach, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
             "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(dom.bytes / max(dom.launches, 1)),
-            "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 / fp16 MFMA 2500 / MFMAs per product (3: split-bf16 x3; 2: the early "
-                          "band's fp16 xh (wh + wl))" if split else "exact-fp32 MFMA peak"),
+            "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 / fp16 MFMA 2500 / MFMAs per product (3: split-bf16 x3; 2 / 1: the early "
+                          "band's fp16 xh (wh + wl) / xh wh)" if split else "exact-fp32 MFMA peak"),
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),
             "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
             "conv_time_share": round(conv_ms * 1e-3 / (prof_steps * sec_per_step), 4),
@@ -513,15 +518,16 @@ def main():
             "metric": "denoised Hi-C tiles/sec (1000-step reverse)", "value": round(value, 4), "unit": "tiles/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "strong" if args.total_tiles else "weak", "vs_baseline": None,
-            "dtype": ("f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate" + ("; 3x3 convs of the steps t >= T/2: two fp16 MFMAs per product" if early else "") + ")")
+            "dtype": ("f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate" + ("; 3x3 convs of the steps t >= T/2: two fp16 MFMAs per product, t >= 3T/4: one" if early else "") + ")")
                      if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
                                    f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
                        "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
                        "chains": chains,
                        **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
-                       "precision_schedule": (f"3x3 convs: two fp16 products per multiply for t >= {int(diff.early_band_from * T_CHAIN)}, split-bf16 x3 below "
-                                              f"({early} of the {len(timed)} timed steps in the early band)" if early else "split-bf16 x3 at every step"),
+                       "precision_schedule": (f"3x3 convs: one fp16 product per multiply for t >= {int(diff.early_band_x1_from * T_CHAIN)}, two for t >= "
+                                              f"{int(diff.early_band_from * T_CHAIN)}, split-bf16 x3 below ({early} of the {len(timed)} timed steps in the early band, "
+                                              f"{sum(1 for p in per_product if p == 1.0)} of them on one product)" if early else "split-bf16 x3 at every step"),
                        "timed_region": ("one whole chain, t = 999 .. 0" if args.steps >= T_CHAIN else
                                         f"{args.steps} steps spread evenly over the chain, t = 999, {timed[1] if len(timed) > 1 else 999}, ... (a stratified sample: "
                                         "the two halves of the chain cost differently; see `sustained` for a whole chain)")},

@@ -132,11 +132,12 @@ class DiffusionCore(nn.Module):
 
         # sampling knobs that do not exist upstream
         # Precision schedule of the ancestral chain: in the first half of a long chain (t >= T / 2, T >= 500) the
-        # UNet's 3x3 convolutions run on two fp16 products per multiply instead of three bf16 ones -- the chain damps what that costs
+        # 3x3 convolutions run on two fp16 products per multiply instead of three bf16 ones, in its first quarter on one -- the chain damps what that costs
         # (tests/studies/error_budget_study.py; tests/test_gpu_timed_path.py::test_full_length_chain_drift_vs_oracle holds the bound).
         # False: split-bf16 x3 at every step.  HICDIFF_EARLY_F16=0 turns it off for a process.
         self.early_band_f16 = os.environ.get("HICDIFF_EARLY_F16", "1") != "0"
         self.early_band_from = 0.5   # the band is t >= early_band_from * T (measured: profiles/r04_e_early_band_drift.txt)
+        self.early_band_x1_from = 0.75  # inside the band, t >= early_band_x1_from * T takes ONE fp16 product, xh wh (> 1: never); measured: r04_j
         self.noise_source = None     # None: device Philox; or an object with .randn(shape) -> device tensor
         self.seed = 1234             # Philox key for device noise
         self.tile_offset = 0         # global index of this rank's first tile (sharded sampling)
@@ -234,7 +235,9 @@ class DiffusionCore(nn.Module):
             c.time_value = float(np.float32(self.sqrt_alphas_cumprod_prev[t_idx + 1].item()))
         else:
             c.time_value = float(t_idx)
-        c.arith = L.HD_ARITH_F16W2 if self._early_band(t_idx) else L.HD_ARITH_DEFAULT
+        c.arith = L.HD_ARITH_DEFAULT
+        if self._early_band(t_idx):
+            c.arith = L.HD_ARITH_F16W1 if t_idx >= int(self.early_band_x1_from * self.num_timesteps) else L.HD_ARITH_F16W2
         return c
 
     def _early_band(self, t_idx: int) -> bool:

@@ -16,8 +16,8 @@ LIB_PATH = os.environ.get("HICDIFF_HIP_LIB") or os.path.join(_HERE, "libhicdiff_
 HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -4, -5
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
-HD_PRECISION_F32, HD_PRECISION_BF16X3, HD_PRECISION_F16W2 = 0, 1, 2
-HD_ARITH_DEFAULT, HD_ARITH_F16W2 = 0, 1      # hd_ddpm_coef.arith
+HD_PRECISION_F32, HD_PRECISION_BF16X3, HD_PRECISION_F16W2, HD_PRECISION_F16W1 = 0, 1, 2, 3
+HD_ARITH_DEFAULT, HD_ARITH_F16W2, HD_ARITH_F16W1 = 0, 1, 2      # hd_ddpm_coef.arith
 HD_TRAIN_PREC_BF16 = 2
 HD_PROFILE_MAX_ROWS = 96
 

@@ -11,10 +11,22 @@
     conv_igemm_f16w2_kernel<WM, WN, TM, TN, 16, MAXI, MODE, 9>,                                                    \
         conv_prof_name("conv_igemm_f16w2_kernel<" #WM ", " #WN ", " #TM ", " #TN ", 16, " #MAXI ", ", MODE, ", 9>")
 
+#define KF161(WM, WN, TM, TN, MAXI)                                                                         \
+    conv_igemm_f16w1_kernel<WM, WN, TM, TN, 16, MAXI, MODE, 9>,                                                    \
+        conv_prof_name("conv_igemm_f16w1_kernel<" #WM ", " #WN ", " #TM ", " #TN ", 16, " #MAXI ", ", MODE, ", 9>")
+
 template <int MODE>
 static int launch_mode(ConvLaunch& L, hipStream_t st) {
     const bool t9 = L.k.KH == 3 && L.k.KW == 3 && MODE != IN_LAYERNORM;
     if constexpr (MODE != IN_LAYERNORM) {
+        if constexpr (MODE != IN_AFFINE_SILU_E) if (t9 && L.k.f16w2 == 2) {
+            switch (L.cfg) {
+                case 0: return launch_one(KF161(2, 2, 2, 2, 3), L, st);
+                case 1: return launch_one(KF161(2, 2, 2, 1, 3), L, st);
+                case 2: return launch_one(KF161(4, 1, 2, 2, 3), L, st);
+                default: return launch_one(KF161(4, 2, 2, 2, 2), L, st, 512);
+            }
+        }
         if constexpr (MODE != IN_AFFINE_SILU_E) if (t9 && L.k.f16w2) {
             switch (L.cfg) {
                 case 0: return launch_one(KF16(2, 2, 2, 2, 3), L, st);

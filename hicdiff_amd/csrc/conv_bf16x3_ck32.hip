@@ -10,12 +10,24 @@
     conv_igemm_f16w2_kernel<WM, WN, TM, TN, 32, MAXI, MODE, 9>,                                                    \
         conv_prof_name("conv_igemm_f16w2_kernel<" #WM ", " #WN ", " #TM ", " #TN ", 32, " #MAXI ", ", MODE, ", 9>")
 
+#define KF321(WM, WN, TM, TN, MAXI)                                                                         \
+    conv_igemm_f16w1_kernel<WM, WN, TM, TN, 32, MAXI, MODE, 9>,                                                    \
+        conv_prof_name("conv_igemm_f16w1_kernel<" #WM ", " #WN ", " #TM ", " #TN ", 32, " #MAXI ", ", MODE, ", 9>")
+
 template <int MODE>
 static int launch_mode(ConvLaunch& L, hipStream_t st) {
     const bool t9 = L.k.KH == 3 && L.k.KW == 3 && MODE != IN_LAYERNORM && MODE != IN_SOFTMAX32;
     const int nt = L.cfg == 3 ? 512 : 256;
     const int need = (L.k.npx * 4 + nt - 1) / nt;
     if constexpr (MODE != IN_LAYERNORM && MODE != IN_SOFTMAX32) {
+        if constexpr (MODE != IN_AFFINE_SILU_E) if (t9 && L.k.f16w2 == 2) {       // one fp16 product per multiply
+            switch (L.cfg) {
+                case 0: return need <= 3 ? launch_one(KF321(2, 2, 2, 2, 3), L, st) : launch_one(KF321(2, 2, 2, 2, 5), L, st);
+                case 1: return need <= 3 ? launch_one(KF321(2, 2, 2, 1, 3), L, st) : launch_one(KF321(2, 2, 2, 1, 5), L, st);
+                case 2: return launch_one(KF321(4, 1, 2, 2, 6), L, st);
+                default: return launch_one(KF321(4, 2, 2, 2, 3), L, st, 512);
+            }
+        }
         if constexpr (MODE != IN_AFFINE_SILU_E) if (t9 && L.k.f16w2) {       // two fp16 products per multiply (conv_host.hip decides; the weight pointer is the fp16 image then)
             switch (L.cfg) {
                 case 0: return need <= 3 ? launch_one(KF32(2, 2, 2, 2, 3), L, st) : launch_one(KF32(2, 2, 2, 2, 5), L, st);

@@ -129,7 +129,8 @@ __device__ __forceinline__ void softmax32(float4& v0, float4& v1) {
 // AR (arithmetic of a product): 0 = split-bf16 x3 (hi hi + hi lo + lo hi); 1 = PLAIN, one bf16 MFMA (hi x hi only) -- the optional bf16
 // arithmetic of the training step; 2 = F16W2 (round 4), two fp16 MFMAs xh (wh + wl): the activation is rounded ONCE to fp16 (11 significant
 // bits), the weight image holds fp16 hi | lo of the exact weight -- a third fewer MFMAs and no lo half of the window, for the timestep band
-// whose error the chain damps (tests/studies/error_budget_study.py).  The staging layout is the same in all three.
+// whose error the chain damps (tests/studies/error_budget_study.py); 3 = F16W1, ONE fp16 MFMA xh wh (both operands
+// rounded once; the hi half of the same fp16 weight image) for the earliest quarter of a long chain.  The staging layout is the same in all.
 #ifndef HD_CK16_CAP3
 #define HD_CK16_CAP3 1    // 1: the plain-loader 256 x 64 tile with 16-channel slices is capped at 168 registers (three workgroups per CU)
 #endif
@@ -140,9 +141,9 @@ constexpr bool conv_cap3() { return HD_CK16_CAP3 && NTAPS == 9 && CK == 16 && WM
 #endif
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS, int AR, bool FBWD = false>
 __device__ __forceinline__ void conv_igemm_bf16x3_body(ConvKArgs p) {
-    constexpr bool F16 = AR == 2;
+    constexpr bool F16 = AR >= 2;
     constexpr bool ALO = AR == 0;                      // the window carries a lo half
-    constexpr bool BLO = AR != 1;                      // the weight fragments carry a lo half
+    constexpr bool BLO = AR == 0 || AR == 2;           // the weight fragments carry a lo half
     constexpr int NT = 64 * WM * WN;                   // 4 waves (256 threads) or 8 waves (512 threads)
     constexpr bool M16 = CK == 32 && NTAPS == 9 && HD_MFMA16;   // 16 x 16 x 32 MFMA tiles (one instruction covers the whole 32-channel slice); the 1x1 kernels measured 5-12 % slower on it
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, PITCH = M16 ? 160 : 4 * CK + 16;
@@ -692,6 +693,12 @@ template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 __global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>() ? 3 : 2)) void conv_igemm_f16w2_kernel(ConvKArgs p) {
     static_assert(NTAPS == 9, "3x3 kernels only");
     conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, 2>(p);
+}
+// one fp16 product per multiply, xh wh
+template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
+__global__ __launch_bounds__(64 * WM * WN, (conv_cap3<WM, WN, CK, MODE, NTAPS>() ? 3 : 2)) void conv_igemm_f16w1_kernel(ConvKArgs p) {
+    static_assert(NTAPS == 9, "3x3 kernels only");
+    conv_igemm_bf16x3_body<WM, WN, TM, TN, CK, MAXI, MODE, NTAPS, 3>(p);
 }
 template <int WM, int WN, int TM, int TN, int CK, int MAXI, int MODE, int NTAPS>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_bf16_kernel(ConvKArgs p) {

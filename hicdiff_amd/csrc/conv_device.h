@@ -48,7 +48,7 @@ struct ConvKArgs {
     int ksplit, kchunks;         // bf16x3 3x3 kernel: split-K over grid.y (1: off); K slices per split
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
     int m16;      // bf16x3 kernel family: 1 = the launch runs on 16 x 16 MFMA tiles (row -> pixel maps are laid out for 16-row operand blocks)
-    int f16w2;    // bf16x3 kernel family, 3x3 kernels: 1 = two fp16 products per multiply, xh (wh + wl); wsplit then points at the fp16 image
+    int f16w2;    // bf16x3 kernel family, 3x3 kernels: 1 = two fp16 products per multiply, xh (wh + wl); 2 = one, xh wh; wsplit then points at the fp16 image
     int plain;    // bf16x3 kernel family: 1 = one bf16 MFMA per product (training's optional bf16 arithmetic; 8-wave 3x3 variant only)
 #ifdef HD_STAMPS
     unsigned long long* stamps;   // timing study builds only (make EXTRA=-DHD_STAMPS): [4096][16] cycle stamps, see conv_bf16x3_kernel.h

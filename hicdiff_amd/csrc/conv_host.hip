@@ -327,8 +327,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     k.plain = a.plain_bf16;
     // two fp16 products per multiply: 3x3 layers that carry the fp16 image, shared weights, none of the training-only forms
-    k.f16w2 = a.f16w2 && a.cw.wsplit16 && a.cw.KH == 3 && a.cw.KW == 3 && !a.w_bstride && !a.plain_bf16 && !(a.ep & EP_FILM_SILU_BWD) &&
+    const bool f16ok = a.f16w2 && a.cw.wsplit16 && a.cw.KH == 3 && a.cw.KW == 3 && !a.w_bstride && !a.plain_bf16 && !(a.ep & EP_FILM_SILU_BWD) &&
               a.in_mode != IN_LAYERNORM && a.in_mode != IN_SOFTMAX32 && !(a.in_mode == IN_AFFINE_SILU && a.inE) && a.precision == HD_PREC_BF16X3;
+    k.f16w2 = f16ok ? (a.f16w2 >= 2 ? 2 : 1) : 0;             // 1: xh (wh + wl), 2: xh wh
     // (the SR3 blocks' loader with the additive term keeps three products: its 256 x 64 instantiation does not fit the registers without scratch)
     if (k.f16w2) k.wsplit = a.cw.wsplit16;
     k.m16 = 0;

@@ -114,7 +114,7 @@ struct hd_ctx {
     float* eps_buf = nullptr; size_t eps_cap = 0;   // eps of the fused step calls
     int resB = 0, resS = 0;
     int precision = HD_PREC_BF16X3;   // arithmetic of the wide convolutions (hd_set_precision)
-    int f16w2 = 0;                    // with BF16X3: the 3x3 convolutions take two fp16 products per multiply (HD_PRECISION_F16W2, or one step's hd_ddpm_coef.arith)
+    int f16w2 = 0;                    // with BF16X3: the 3x3 convolutions take two (1) / one (2) fp16 products per multiply (HD_PRECISION_F16W2 / _F16W1, or one step's hd_ddpm_coef.arith)
     int ck = 16;                      // K slice of the split-bf16 weights: 32 when every channel count allows it
     // hipGraph replay of the fused sampler steps (device-generated noise only): one graph per
     // (kind, B, S, tensor addresses); the step's scalars are written to the lane's `sp_dev` by a 1-thread kernel.
@@ -971,7 +971,7 @@ static int lanes_join(hd_ctx* c, hipStream_t user) {
 static int lane_step(hd_ctx* c, hd_ctx::Lane& L, Pool* pool, int kind, float* x, const float* aux, const StepParams& v, float* x0_out, float* eps,
                      int B, int S) {
     hd_ctx::StepGraph* g = nullptr;
-    const int arith = c->precision == HD_PREC_BF16X3 && c->f16w2 ? 2 : c->precision;     // a captured step holds the kernels of the arithmetic it was captured under
+    const int arith = c->precision == HD_PREC_BF16X3 && c->f16w2 ? 1 + c->f16w2 : c->precision;     // a captured step holds the kernels of the arithmetic it was captured under
     for (auto& e : L.graphs) if (e.kind == kind && e.B == B && e.S == S && e.precision == arith && e.x == x && e.aux == aux && e.x0 == x0_out) { g = &e; break; }
     if (!g) {
         if (L.graphs.size() >= 16) {        // callers that pass fresh tensors every step must not grow the cache
@@ -1056,8 +1056,8 @@ int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, con
     v.step = step; v.seed = seed; v.tile_off = tile_offset;
     // this step's arithmetic (hd_ddpm_coef.arith): the host's precision schedule over the chain
     const int saved = c->f16w2;
-    if (k->arith == HD_ARITH_F16W2 && c->precision == HD_PREC_BF16X3) c->f16w2 = 1;
-    else if (k->arith > HD_ARITH_F16W2) return fail(c, HD_EINVAL, "hd_ddpm_coef.arith: unknown value");
+    if (k->arith > HD_ARITH_F16W1) return fail(c, HD_EINVAL, "hd_ddpm_coef.arith: unknown value");
+    if (k->arith != HD_ARITH_DEFAULT && c->precision == HD_PREC_BF16X3) c->f16w2 = (int)k->arith;
     const int rc = run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream);
     c->f16w2 = saved;
     return keep_err(c, rc);
@@ -1163,11 +1163,11 @@ int hd_stitch_pieces(const float* tiles, const int* tile_of, int nb, int piece, 
 int hd_profile_enable(int enable) { hd_prof_enable(enable != 0); return HD_OK; }
 
 int hd_set_precision(hd_ctx* c, int mode) {
-    if (!c || (mode != HD_PREC_F32 && mode != HD_PREC_BF16X3 && mode != 2 /* HD_PRECISION_F16W2 */)) return HD_EINVAL;
+    if (!c || mode < 0 || mode > 3 /* HD_PRECISION_F16W1 */) return HD_EINVAL;
     // a captured step holds the kernels of the arithmetic it was captured under: the graph cache is keyed by the mode (run_step), so a
     // sampler that switches back and forth (ddim_sample runs exact fp32) keeps both sets instead of re-capturing every time
-    c->precision = mode == 2 ? HD_PREC_BF16X3 : mode;
-    c->f16w2 = mode == 2;
+    c->precision = mode >= 2 ? HD_PREC_BF16X3 : mode;
+    c->f16w2 = mode >= 2 ? mode - 1 : 0;          // 1: two fp16 products in the 3x3 convolutions, 2: one
     return HD_OK;
 }
 
@@ -1297,7 +1297,7 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
     if ((mode & 512) && (mode & 32) && rc == 0) {          // two fp16 products per multiply (3x3 only; launch_conv falls back to x3 where it does not apply)
         if (KH != 3 || unsh || Cin % 16 || hipMalloc(&psplit16, (size_t)9 * Cin * cw.CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) rc = HD_EINVAL;
         if (rc == 0) rc = launch_split_conv(cw.w, (unsigned short*)psplit16, 9, Cin, cw.CoutPad, 16, st, 1);
-        a.cw.wsplit16 = (unsigned short*)psplit16; a.f16w2 = 1;
+        a.cw.wsplit16 = (unsigned short*)psplit16; a.f16w2 = (mode & 1024) ? 2 : 1;      // 1024: ONE fp16 product, xh wh
     }
     void* pwino = nullptr;
     if ((mode & 256) && rc == 0) {             // Winograd image + switch: launch_conv takes the F(2x2,3x3) kernel where the shape allows it

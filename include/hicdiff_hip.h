@@ -98,10 +98,11 @@ typedef struct {
     float eps_coef;                      /* weight of eps itself in the update; 0 for the ancestral step.  A DDIM step (src/hicdiff.py:622-664) is
                                             coef1 = sqrt(alpha_next), coef2 = 0, eps_coef = sqrt(1 - alpha_next - sigma^2), sigma = eta-term */
     uint32_t arith;                      /* arithmetic of THIS step's 3x3 convolutions: HD_ARITH_DEFAULT (the context's, hd_set_precision) or
-                                            HD_ARITH_F16W2 (two fp16 products per multiply; only on a context in HD_PRECISION_BF16X3).  The host's
+                                            HD_ARITH_F16W2 / HD_ARITH_F16W1 (two / one fp16 products per multiply, xh (wh + wl) / xh wh; only on a
+                                            context in HD_PRECISION_BF16X3).  The host's
                                             precision schedule over a chain: hicdiff_amd/_diffusion.py, DESIGN.md section 4e */
 } hd_ddpm_coef;
-enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1 };
+enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1, HD_ARITH_F16W1 = 2 };
 
 /* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
 typedef struct {
@@ -147,8 +148,9 @@ int hd_workspace_bytes(const hd_ctx* ctx, int B, int S, size_t* out);
  *                        once to fp16, the weight exact -- ~1e-3 per forward, i.e. NOT inside the parity bound as a whole-chain mode;
  *                        it exists for the early half of a long ancestral chain, where the chain damps the error (the per-step
  *                        switch hd_ddpm_coef.arith is what the samplers use), and as a context-wide mode for tests and measurements.
+ *   HD_PRECISION_F16W1   the same with ONE fp16 product, xh wh (weights rounded to fp16 as well): the earliest quarter of a long chain.
  * The environment variable HICDIFF_PRECISION=f32|bf16x3 sets the default at hd_create. */
-enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1, HD_PRECISION_F16W2 = 2 };
+enum { HD_PRECISION_F32 = 0, HD_PRECISION_BF16X3 = 1, HD_PRECISION_F16W2 = 2, HD_PRECISION_F16W1 = 3 };
 int hd_set_precision(hd_ctx* ctx, int mode);
 
 /* ---- DDRM with a general degradation H = U S V^T (src/functions/denoising.py:11-111 over the operators of

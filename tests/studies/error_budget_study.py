@@ -53,12 +53,18 @@ def conv_a1w2(x, w, stride, padding):
     return c(xh, wh) + c(xh, wl)
 
 
+def conv_x1(x, w, stride, padding):
+    """fp16 x fp16, one product: both operands rounded once."""
+    return _conv2d(x.to(torch.float16).float(), w.to(torch.float16).float(), None, stride, padding)
+
+
 class Router:
     """F.conv2d stand-in inside oracle.nets: wide convolutions (>= 64 input channels) go through x3 or, in the cells of `policy`
     (set of (band, class)), through fp16 a1w2.  Counts MFMA work (products x flops) per cell."""
 
-    def __init__(self, S, T, policy):
+    def __init__(self, S, T, policy, x1_cells=()):
         self.S, self.T, self.policy, self.t = S, T, policy, 0
+        self.x1_cells = set(x1_cells)   # cells that take ONE fp16 product instead (the --x1 experiment)
         self.work = {}                  # (band, class) -> algorithmic flops of the wide convolutions
 
     def cell(self, x):
@@ -70,7 +76,7 @@ class Router:
         if w.shape[1] < 64 or groups != 1:
             return _conv2d(x, w, b, stride, padding, dilation, groups)
         cell = self.cell(x)
-        y = (conv_a1w2 if cell in self.policy else conv_x3)(x, w, stride, padding)
+        y = (conv_x1 if cell in self.x1_cells else conv_a1w2 if cell in self.policy else conv_x3)(x, w, stride, padding)
         self.work[cell] = self.work.get(cell, 0.0) + 2.0 * y.numel() * w.shape[1] * w.shape[2] * w.shape[3]
         return y if b is None else y + b.view(1, -1, 1, 1)
 
@@ -100,6 +106,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--full", action="store_true", help="T = 1000 at 40 x 40 (the drift test's chain); band / cumulative policies only")
     ap.add_argument("--threads", type=int, default=4)
+    ap.add_argument("--x1", action="store_true", help="only the three-tier experiment: ONE fp16 product in band 3 (and in bands 3 + 2), two products in band 2")
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
     from _util import oracle_unet
@@ -119,9 +126,14 @@ def main():
     policies += [(f"bands >= {b}, all classes", {(bb, c) for bb in bands if bb >= b for c in all_cls}) for b in (2, 1)]
     policies += [(f"class {c}, all bands", {(b, c) for b in bands}) for c in CLASSES]
     policies += [("everything (section 4d)", {(b, c) for b in bands for c in all_cls})]
+    x1 = {}
+    if args.x1:
+        b3, b2 = {(3, c) for c in all_cls}, {(2, c) for c in all_cls}
+        policies = [("x3 everywhere (product)", set()), ("band 3: x1, band 2: a1w2", b3 | b2), ("band 3: x1 only", b3), ("bands 3, 2: x1", b3 | b2)]
+        x1 = {"band 3: x1, band 2: a1w2": b3, "band 3: x1 only": b3, "bands 3, 2: x1": b3 | b2}
     total = None
     for name, pol in policies:
-        r = Router(S, T, pol)
+        r = Router(S, T, pol, x1.get(name, ()))
         t0 = time.time()
         got = run_chain(model, S, T, B, 11, r)
         if total is None:

@@ -493,6 +493,16 @@ def test_conv3x3_two_fp16_products(B, S, Cin, Cout, ck):
     assert torch.equal(got, run_conv(x, None, w, b, 3, 512 | ck))
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout", [(2, 16, 64, 64), (1, 64, 64, 64), (3, 8, 128, 256), (1, 32, 128, 256), (2, 64, 128, 64)])
+def test_conv3x3_one_fp16_product(B, S, Cin, Cout):
+    """AR = 3, xh wh: against torch conv2d of the fp16-rounded activations AND fp16-rounded weights (what the mode is defined as)."""
+    x, w, b = rnd(1, B, Cin, S, S), rnd(2, Cout, Cin, 3, 3) / (3 * Cin ** 0.5), rnd(3, Cout)
+    got = run_conv(x, None, w, b, 3, 1024 | 512 | 96)
+    assert rel_err(F.conv2d(x.half().float(), w.half().float(), b, padding=1), got) < 1e-4
+    assert rel_err(F.conv2d(x, w, b, padding=1), got) < 3e-3
+    assert torch.equal(got, run_conv(x, None, w, b, 3, 1024 | 512 | 96))
+
+
 def test_conv3x3_two_fp16_products_loaders_and_geometry():
     """GroupNorm-apply + SiLU loader (rounding happens AFTER the transform), concat of two sources, nearest-x2 upsample."""
     B, Cc, S = 3, 64, 32

@@ -572,26 +572,29 @@ def test_full_length_chain_drift_vs_oracle(precision, capsys):
 
 
 def test_early_band_schedule_is_what_the_long_chain_runs_and_nothing_else():
-    """The precision schedule (hicdiff_amd/_diffusion.py:_early_band): two fp16 products in the 3x3 convolutions for t >= T / 2 of chains of
-    at least 500 steps; 50-step chains, the second half, a network that opts out and a switched-off schedule keep three products."""
+    """The precision schedule (hicdiff_amd/_diffusion.py:_early_band): in the 3x3 convolutions one fp16 product for t >= 3T / 4 and two for
+    T / 2 <= t < 3T / 4 of chains of at least 500 steps; 50-step chains, the second half, a network that opts out and a switched-off schedule keep three products."""
     from hicdiff_amd import _lib as L
     d = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
-    assert [d._coef(t).arith for t in (999, 500, 499, 0)] == [L.HD_ARITH_F16W2, L.HD_ARITH_F16W2, L.HD_ARITH_DEFAULT, L.HD_ARITH_DEFAULT]
+    assert [d._coef(t).arith for t in (999, 750, 749, 500, 499, 0)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2,
+                                                                       L.HD_ARITH_DEFAULT, L.HD_ARITH_DEFAULT]
     d.early_band_f16 = False
     assert d._coef(999).arith == L.HD_ARITH_DEFAULT
     d50 = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=50, loss_type="l2", beta_schedule="linear").cuda()
     assert d50._coef(49).arith == L.HD_ARITH_DEFAULT
     dh = diffusion_class("uncond")(product_hicedrn("uncond", 2), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
-    assert dh._coef(999).arith == L.HD_ARITH_F16W2 and dh._coef(499).arith == L.HD_ARITH_DEFAULT
+    assert dh._coef(999).arith == L.HD_ARITH_F16W1 and dh._coef(600).arith == L.HD_ARITH_F16W2 and dh._coef(499).arith == L.HD_ARITH_DEFAULT
     dh.model.EARLY_BAND_OK = False                      # a network opts out by its class attribute
     assert dh._coef(999).arith == L.HD_ARITH_DEFAULT
     # one step each way on the same state: the early-band step differs from the three-product step (the switch is live) within its own bound
     x = device_randn(4, 16, 1, 0, 1000)
     d.early_band_f16 = True
-    a, _ = d.p_sample(x, 900)
+    a, _ = d.p_sample(x, 900)                          # one product
+    a2, _ = d.p_sample(x, 600)                         # two
     d.early_band_f16 = False
     b, _ = d.p_sample(x, 900)
-    assert not torch.equal(a, b) and rel_err(b, a) < 1e-3
+    b2, _ = d.p_sample(x, 600)
+    assert not torch.equal(a, b) and rel_err(b, a) < 1e-3 and not torch.equal(a2, b2) and rel_err(b2, a2) < 1e-3
 
 
 @pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])
@@ -609,9 +612,12 @@ def test_two_product_forward_vs_oracle(kind):
     base = m(x.cuda(), t.cuda(), None if cond is None else cond.cuda())
     eng.set_precision(L.HD_PRECISION_F16W2)
     got = m(x.cuda(), t.cuda(), None if cond is None else cond.cuda())
+    eng.set_precision(L.HD_PRECISION_F16W1)
+    got1 = m(x.cuda(), t.cuda(), None if cond is None else cond.cuda())
     eng.set_precision(L.HD_PRECISION_BF16X3)
     assert rel_err(want, base) < 1e-4
     assert 1e-5 < rel_err(want, got) < 3e-3
+    assert 1e-5 < rel_err(want, got1) < 6e-3 and not torch.equal(got, got1)          # one fp16 product: the weights are rounded as well
 
 
 def test_full_length_hicedrn_chain_drift_vs_oracle(capsys):

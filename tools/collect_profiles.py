@@ -7,9 +7,9 @@ It runs, each as its own rocprofv3 invocation (counters never share a run with -
 itself, no wrapper):
   1. rocprofv3 --kernel-trace --stats  -- python3 bench.py --sustained-budget 0        kernel_stats.csv + the bench JSON line
   2. rocprofv3 --kernel-trace --stats  -- python3 bench.py --workload hicedrn64 --steps 5 --warmup 1
-  3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
-  4. rocprofv3 --kernel-trace --pmc WRITE_SIZE  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
-  5./6. rocprofv3 --kernel-trace --pmc <SQ counters, two passes>  -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+  3. rocprofv3 --kernel-trace --pmc FETCH_SIZE  -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1
+  4. rocprofv3 --kernel-trace --pmc WRITE_SIZE  -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1
+  5./6. rocprofv3 --kernel-trace --pmc <SQ counters, two passes>  -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1
         -> <tag>_unet64_b256_sq.json: per kernel and launch MFMA-busy, wave wait / issue-stall shares, LDS busy and bank-conflict share
 and reduces 3 + 4 to <tag>_unet64_b256_hbm_traffic.json: per kernel, bytes per launch = 1024 * counter / launches, FETCH_SIZE
 doubled (gfx950 tallies 128-byte read requests at 64 bytes: /opt/skills/guides/MI355X_MICROARCH.md, HBM).
@@ -96,7 +96,8 @@ def main():
     rocprof(os.path.join(work, "unet64"), ["--stats"], ["--sustained-budget", "0"], os.path.join(work, "unet64.log"))
     rocprof(os.path.join(work, "hicedrn64"), ["--stats"], ["--workload", "hicedrn64", "--steps", "5", "--warmup", "1", "--sustained-budget", "0"],
             os.path.join(work, "hicedrn64.log"))
-    short = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--sustained-budget", "0"]
+    # counter passes: one whole-batch chain, so that a launch is the 256-tile launch the bench line's algorithmic bytes describe
+    short = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--sustained-budget", "0", "--chains", "1"]
     rocprof(os.path.join(work, "fetch"), ["--pmc", "FETCH_SIZE"], short, os.path.join(work, "fetch.log"))
     rocprof(os.path.join(work, "write"), ["--pmc", "WRITE_SIZE"], short, os.path.join(work, "write.log"))
     if "--no-sq" not in sys.argv:
@@ -104,7 +105,7 @@ def main():
         rocprof(os.path.join(work, "sqb"), ["--pmc"] + SQ_B, short, os.path.join(work, "sqb.log"))
         sq_reduce([os.path.join(work, "sqa", "p_counter_collection.csv"), os.path.join(work, "sqb", "p_counter_collection.csv")],
                   os.path.join(out, f"{tag}_unet64_b256_sq.json"),
-                  "rocprofv3 --kernel-trace --pmc " + " ".join(SQ_A) + " | " + " ".join(SQ_B) + " (one pass each) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+                  "rocprofv3 --kernel-trace --pmc " + " ".join(SQ_A) + " | " + " ".join(SQ_B) + " (one pass each) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1")
     for wl in ("unet64", "hicedrn64"):
         shutil.copy(os.path.join(work, wl, "p_kernel_stats.csv"), os.path.join(out, f"{tag}_{wl}_b256_kernel_stats.csv"))
         with open(os.path.join(work, wl + ".log")) as f:
@@ -114,7 +115,7 @@ def main():
                 f.write(lines[-1])
     fe, nf = per_kernel(os.path.join(work, "fetch", "p_counter_collection.csv"), "FETCH_SIZE")
     wr, nw = per_kernel(os.path.join(work, "write", "p_counter_collection.csv"), "WRITE_SIZE")
-    steps = 3 + 1 + 3            # timed + warm-up + the profiled eager steps bench.py adds
+    steps = 9 + 1 + 4 + 4        # graph set-up (3 per arithmetic) + warm-up + timed + the profiled eager steps bench.py adds
     rows, tf, tw = [], 0.0, 0.0
     for k in fe:
         fb, wb = 2 * fe[k] * 1024, wr.get(k, 0.0) * 1024
@@ -122,7 +123,7 @@ def main():
         tw += wb
         rows.append((k, nf[k], fb / nf[k], wb / max(nw.get(k, 1), 1)))
     rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
-    rec = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+    rec = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (one pass each) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1",
            "correction": "bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE): gfx950 FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM)",
            "steps_in_run": steps, "per_step_fetch_GB": round(tf / steps / 1e9, 3), "per_step_write_GB": round(tw / steps / 1e9, 3),
            "kernels": {k: {"launches": n, "fetch_bytes_per_launch": round(fb), "write_bytes_per_launch": round(wb)} for k, n, fb, wb in rows}}

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--only", default="")
     ap.add_argument("--f16w2", action="store_true", help="3x3 shapes with two fp16 products per multiply (mode bit 512)")
+    ap.add_argument("--f16w1", action="store_true", help="3x3 shapes with ONE fp16 product per multiply (mode bits 512 | 1024)")
     ap.add_argument("--zeros", action="store_true", help="all-zero activations and weights: the same instruction stream at the clock the chip holds on trivial data (DVFS check)")
     a = ap.parse_args()
     from hicdiff_amd import _lib as L
@@ -56,8 +57,8 @@ def main():
         if a.only and a.only not in name:
             continue
         B = a.B
-        if a.f16w2 and K == 3:
-            mode |= 512
+        if (a.f16w2 or a.f16w1) and K == 3:
+            mode |= 512 | (1024 if a.f16w1 else 0)
         x0 = torch.randn((B, S, S, C0), device="cuda", generator=g)
         x1 = torch.randn((B, S, S, C1), device="cuda", generator=g) if C1 else None
         cin = C0 + C1
@@ -88,7 +89,7 @@ def main():
         times.sort()
         us, kern, fl = times[len(times) // 2]
         total += us
-        print(f"{name:28s} {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s-eq  min {times[0][0]:8.1f}  {kern.replace('conv_igemm_bf16x3_kernel', 'k').replace('conv_igemm_f16w2_kernel', 'kf16')}")
+        print(f"{name:28s} {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s-eq  min {times[0][0]:8.1f}  {kern.replace('conv_igemm_bf16x3_kernel', 'k').replace('conv_igemm_f16w2_kernel', 'kf16').replace('conv_igemm_f16w1_kernel', 'kf16x1')}")
     print(f"{'sum':28s} {total:8.1f} us   [lib '{a.lib or 'product'}', B={a.B}]")
 
 
