@@ -137,6 +137,9 @@ class DiffusionCore(nn.Module):
         # False: split-bf16 x3 at every step.  HICDIFF_EARLY_F16=0 turns it off for a process.
         self.early_band_f16 = os.environ.get("HICDIFF_EARLY_F16", "1") != "0"
         self.early_band_from = 0.5   # the band is t >= early_band_from * T (measured: profiles/r04_e_early_band_drift.txt)
+        # below the band: two products on the 3x3 layers of the feature maps of at most (S/4)^2 pixels -- the study's "low" layer class, 42 % of the
+        # matrix work, which the late half of the chain tolerates where the full-resolution layers do not (profiles/r04_m_*); HICDIFF_LATE_LOW_F16=0: off
+        self.late_band_low_f16 = os.environ.get("HICDIFF_LATE_LOW_F16", "1") != "0"
         self.early_band_x1_from = 0.75  # inside the band, t >= early_band_x1_from * T takes ONE fp16 product, xh wh (> 1: never); measured: r04_j
         self.noise_source = None     # None: device Philox; or an object with .randn(shape) -> device tensor
         self.seed = 1234             # Philox key for device noise
@@ -236,6 +239,8 @@ class DiffusionCore(nn.Module):
         else:
             c.time_value = float(t_idx)
         c.arith = L.HD_ARITH_DEFAULT
+        if self.late_band_low_f16 and self._early_band(self.num_timesteps - 1):
+            c.arith = L.HD_ARITH_F16W2_LOW
         if self._early_band(t_idx):
             c.arith = L.HD_ARITH_F16W1 if t_idx >= int(self.early_band_x1_from * self.num_timesteps) else L.HD_ARITH_F16W2
         return c

@@ -17,7 +17,7 @@ HD_OK, HD_EINVAL, HD_ENOWEIGHT, HD_EHIP, HD_ENOMEM, HD_ESTATE = 0, -1, -2, -3, -
 HD_ARCH_UNET, HD_ARCH_HICEDRN = 0, 1
 HD_T_INT64, HD_T_FLOAT32 = 0, 1
 HD_PRECISION_F32, HD_PRECISION_BF16X3, HD_PRECISION_F16W2, HD_PRECISION_F16W1 = 0, 1, 2, 3
-HD_ARITH_DEFAULT, HD_ARITH_F16W2, HD_ARITH_F16W1 = 0, 1, 2      # hd_ddpm_coef.arith
+HD_ARITH_DEFAULT, HD_ARITH_F16W2, HD_ARITH_F16W1, HD_ARITH_F16W2_LOW = 0, 1, 2, 3      # hd_ddpm_coef.arith
 HD_TRAIN_PREC_BF16 = 2
 HD_PROFILE_MAX_ROWS = 96
 

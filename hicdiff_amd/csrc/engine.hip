@@ -418,10 +418,18 @@ static void pick_slices(ConvArgs& a) {
     if (ck16n && a.cw.KH == 3 && a.cw.KW == 3 && a.cw.CoutPad == 64 && a.cw.ck == 32 && a.H * a.W >= 4096 && a.in_mode == IN_NONE) a.cw.ck = 16;
 }
 
+// The arithmetic of one 3x3 layer under the context's level: 1 / 2 = two / one fp16 products everywhere, 3 = two products on the maps of at
+// most (S/4)^2 pixels only (the "low" layer class of the error-budget study: the layers whose error the LATE half of a chain tolerates).
+static int layer_f16(const Run& r, const ConvArgs& a) {
+    const int lvl = r.c->f16w2;
+    if (lvl != 3) return lvl;
+    return (long long)a.H * a.W * 16 <= (long long)r.S * r.S ? 1 : 0;
+}
+
 static int run_conv(Run& r, ConvArgs& a) {
     pick_slices(a);
     a.precision = r.c->precision;
-    a.f16w2 = r.c->f16w2;
+    a.f16w2 = layer_f16(r, a);
     // the dry run sizes the workspace for either arithmetic (hd_set_precision may switch later): plan the split as the fast path would
     ConvArgs probe = a; probe.precision = HD_PREC_BF16X3;
     const int ks = conv_splitk(probe);
@@ -440,7 +448,7 @@ static int conv_gn(Run& r, ConvArgs& a, int C, const float* gamma, const float* 
     const int HW = a.H * a.W;
     pick_slices(a);
     a.precision = r.c->precision;
-    a.f16w2 = r.c->f16w2;
+    a.f16w2 = layer_f16(r, a);
     int slots = conv_gn_slots(a);
     const bool fused = slots > 0;
     if (!fused) slots = (HW + 255) / 256;
@@ -1056,7 +1064,7 @@ int hd_ddpm_step(hd_ctx* c, float* x, const float* cond, const float* noise, con
     v.step = step; v.seed = seed; v.tile_off = tile_offset;
     // this step's arithmetic (hd_ddpm_coef.arith): the host's precision schedule over the chain
     const int saved = c->f16w2;
-    if (k->arith > HD_ARITH_F16W1) return fail(c, HD_EINVAL, "hd_ddpm_coef.arith: unknown value");
+    if (k->arith > HD_ARITH_F16W2_LOW) return fail(c, HD_EINVAL, "hd_ddpm_coef.arith: unknown value");
     if (k->arith != HD_ARITH_DEFAULT && c->precision == HD_PREC_BF16X3) c->f16w2 = (int)k->arith;
     const int rc = run_step(c, 0, x, cond, noise, v, x0_out, B, S, (hipStream_t)stream);
     c->f16w2 = saved;

@@ -102,7 +102,8 @@ typedef struct {
                                             context in HD_PRECISION_BF16X3).  The host's
                                             precision schedule over a chain: hicdiff_amd/_diffusion.py, DESIGN.md section 4e */
 } hd_ddpm_coef;
-enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1, HD_ARITH_F16W1 = 2 };
+enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1, HD_ARITH_F16W1 = 2,
+       HD_ARITH_F16W2_LOW = 3 /* two fp16 products on the feature maps of at most (S/4)^2 pixels, three elsewhere */ };
 
 /* Coefficients of one DDRM 'deno' step (src/functions/denoising.py:48-104 with identity H). */
 typedef struct {

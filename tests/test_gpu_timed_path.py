@@ -577,13 +577,16 @@ def test_early_band_schedule_is_what_the_long_chain_runs_and_nothing_else():
     from hicdiff_amd import _lib as L
     d = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
     assert [d._coef(t).arith for t in (999, 750, 749, 500, 499, 0)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2,
-                                                                       L.HD_ARITH_DEFAULT, L.HD_ARITH_DEFAULT]
+                                                                       L.HD_ARITH_F16W2_LOW, L.HD_ARITH_F16W2_LOW]
+    d.late_band_low_f16 = False
+    assert d._coef(499).arith == L.HD_ARITH_DEFAULT and d._coef(999).arith == L.HD_ARITH_F16W1
+    d.late_band_low_f16 = True
     d.early_band_f16 = False
-    assert d._coef(999).arith == L.HD_ARITH_DEFAULT
+    assert d._coef(999).arith == L.HD_ARITH_DEFAULT and d._coef(10).arith == L.HD_ARITH_DEFAULT
     d50 = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=50, loss_type="l2", beta_schedule="linear").cuda()
     assert d50._coef(49).arith == L.HD_ARITH_DEFAULT
     dh = diffusion_class("uncond")(product_hicedrn("uncond", 2), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear").cuda()
-    assert dh._coef(999).arith == L.HD_ARITH_F16W1 and dh._coef(600).arith == L.HD_ARITH_F16W2 and dh._coef(499).arith == L.HD_ARITH_DEFAULT
+    assert dh._coef(999).arith == L.HD_ARITH_F16W1 and dh._coef(600).arith == L.HD_ARITH_F16W2 and dh._coef(499).arith == L.HD_ARITH_F16W2_LOW   # (hicedrn has no low-resolution maps: three products)
     dh.model.EARLY_BAND_OK = False                      # a network opts out by its class attribute
     assert dh._coef(999).arith == L.HD_ARITH_DEFAULT
     # one step each way on the same state: the early-band step differs from the three-product step (the switch is live) within its own bound
