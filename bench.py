@@ -529,7 +529,7 @@ def main():
                        "chains": chains,
                        **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
                        "precision_schedule": (f"3x3 convs: one fp16 product per multiply for t >= {int(diff.early_band_x1_from * T_CHAIN)}, two for t >= "
-                                              f"{int(diff.early_band_from * T_CHAIN)}, split-bf16 x3 below" +
+                                              f"{int(diff._band_from() * T_CHAIN)}, split-bf16 x3 below" +
                                               (" except two products on the maps of at most (S/4)^2 pixels" if late != 3.0 else "") +
                                               f" ({early} of the {len(timed)} timed steps in the early band, "
                                               f"{sum(1 for p in per_product if p == 1.0)} of them on one product)" if early else "split-bf16 x3 at every step"),

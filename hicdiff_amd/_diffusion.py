@@ -136,7 +136,8 @@ class DiffusionCore(nn.Module):
         # (tests/studies/error_budget_study.py; tests/test_gpu_timed_path.py::test_full_length_chain_drift_vs_oracle holds the bound).
         # False: split-bf16 x3 at every step.  HICDIFF_EARLY_F16=0 turns it off for a process.
         self.early_band_f16 = os.environ.get("HICDIFF_EARLY_F16", "1") != "0"
-        self.early_band_from = 0.5   # the band is t >= early_band_from * T (measured: profiles/r04_e_early_band_drift.txt)
+        # the band is t >= early_band_from * T; None: the network's own figure (UNet 0.5, hicedrn 0: profiles/r04_e_*, r04_p_*)
+        self.early_band_from = None
         # below the band: two products on the 3x3 layers of the feature maps of at most (S/4)^2 pixels -- the study's "low" layer class, 42 % of the
         # matrix work, which the late half of the chain tolerates where the full-resolution layers do not (profiles/r04_m_*); HICDIFF_LATE_LOW_F16=0: off
         self.late_band_low_f16 = os.environ.get("HICDIFF_LATE_LOW_F16", "1") != "0"
@@ -250,7 +251,10 @@ class DiffusionCore(nn.Module):
         their steps is twenty steps' worth of posterior_mean_coef1), their first half only, and networks that declare EARLY_BAND_OK (the UNet: what
         the CPU study and the GPU drift runs covered)."""
         T = self.num_timesteps
-        return bool(self.early_band_f16) and T >= 500 and t_idx >= int(self.early_band_from * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
+        return bool(self.early_band_f16) and T >= 500 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
+
+    def _band_from(self) -> float:
+        return float(getattr(self.model, "EARLY_BAND_FROM", 0.5) if self.early_band_from is None else self.early_band_from)
 
     def _step_inplace(self, img, t_idx: int, cond, x0_out=None, eng=None):
         """img <- p_sample(img, t): one hd_ddpm_step call (eps-net + clamp + posterior + noise).  The three objectives differ only in the two

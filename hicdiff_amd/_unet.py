@@ -8,6 +8,7 @@ from ._specs import unet_specs
 
 
 class UnetBase(EpsNetBase):
+    EARLY_BAND_FROM = 0.5     # the early band of the precision schedule is t >= T / 2
     EARLY_BAND_OK = True      # the samplers' precision schedule applies (hicdiff_amd/_diffusion.py:_early_band; measured: profiles/r04_e_*)
 
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=1, self_condition=False,

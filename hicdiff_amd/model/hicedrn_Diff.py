@@ -13,6 +13,7 @@ kernel_size = 3
 class hicedrn_Diff(EpsNetBase):
     _SR3 = False
     EARLY_BAND_OK = True       # the samplers' precision schedule applies (hicdiff_amd/_diffusion.py:_early_band; profiles/r04_e_*)
+    EARLY_BAND_FROM = 0.0      # ... to every step of a long chain: two fp16 products add 2.4-4.0e-4 here (the UNet: 5.5-8.0e-4), profiles/r04_p_*
     _native_train = True       # hd_train_* covers this network (unconditional and self_condition); see hicdiff_amd/_training.py
 
     def __init__(self, channels=1, out_dim=None, number_resnet=32, self_condition=False,
