@@ -400,3 +400,26 @@ def test_every_rank_runs_the_same_number_of_optimizer_steps():
         flat = sorted(i for p in val for b in p for i in b)
         assert flat == list(range(n))                                          # validation: each tile exactly once, ragged tail kept
     assert train.batch_plan(0, 64, 0, 2, True) == []
+
+
+def test_precision_schedule_policy_on_the_host():
+    """The samplers' precision schedule is host policy (hicdiff_amd/_diffusion.py:_coef -> hd_ddpm_coef.arith): long
+    chains only, per network, switchable.  No GPU needed: the coefficients come from the host copies of the schedule buffers."""
+    from hicdiff_amd import _lib as L
+    from hicdiff_amd.hicdiff import GaussianDiffusion, Unet
+    from hicdiff_amd.model.hicedrn_Diff import hicedrn_Diff
+    u = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear")
+    got = [u._coef(t).arith for t in (999, 750, 749, 500, 499, 0)]
+    assert got == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2_LOW, L.HD_ARITH_F16W2_LOW]
+    u.late_band_low_f16 = False
+    assert u._coef(100).arith == L.HD_ARITH_DEFAULT
+    u.early_band_f16 = False
+    assert {u._coef(t).arith for t in (999, 600, 100)} == {L.HD_ARITH_DEFAULT}
+    short = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=50, loss_type="l2", beta_schedule="linear")
+    assert {short._coef(t).arith for t in range(50)} == {L.HD_ARITH_DEFAULT}                      # 50-step chains keep three products
+    h = GaussianDiffusion(hicedrn_Diff(number_resnet=1), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear")
+    assert [h._coef(t).arith for t in (999, 749, 0)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2]   # hicedrn: the whole chain
+    h.early_band_from = 0.5
+    assert h._coef(0).arith == L.HD_ARITH_F16W2_LOW and h._coef(500).arith == L.HD_ARITH_F16W2
+    import ctypes as C
+    assert C.sizeof(L.HdDdpmCoef) == 36 and C.sizeof(L.HdDdrmCoef) == 44                          # include/hicdiff_hip.h
