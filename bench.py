@@ -345,7 +345,7 @@ def main():
                     help="strong-scaling form (BASELINE configs[3]: 256 hicedrn tiles sharded over the node): the job is this many tiles in all, "
                          "total/N per GPU; reported with \"scaling\": \"strong\"")
     ap.add_argument("--chains", type=int, default=None, choices=[1, 2, 3, 4],
-                    help="force one whole-batch chain or two half-batch chains per GPU (default: the library's rule, two from 512 k pixels per step on)")
+                    help="force one whole-batch chain or two half-batch chains per GPU (default: the library's rule, two for every replayed step: from 150 k pixels per step on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
     ap.add_argument("--full-chain", action="store_true", help="time a whole chain: --steps becomes 1000 (t = 999 .. 0)")

@@ -853,11 +853,18 @@ int hd_load_weights(hd_ctx* c, const hd_named_tensor* tensors, int n, void* stre
     return keep_err(c, rc);
 }
 
-// How a replayed step of B tiles of S x S is cut: two half-batch lanes from 512 k pixels per step on (measured: profiles/r04_a_*), one
+// Replay threshold: steps of at least this many pixels (B * S * S) are replayed from hipGraphs, and as TWO half-batch chains; smaller ones are
+// launched eagerly as one batch.  Measured (profiles/r04_y_replay_threshold.txt): 64 tiles of 40 x 40 (102 k) and 32 of 64 x 64 (131 k) run
+// 2 % faster eagerly, 96 / 128 / 160 tiles of 40 x 40 (154 k / 205 k / 256 k) run 8 / 7 / 13 % faster as two replayed chains -- at those sizes
+// a kernel does not fill the chip and the two chains' launches really run side by side.  (Round 3's threshold, 256 k for one replayed chain, was
+// the cross-over of eager launches against ONE graph.)
+static const long long kReplayMinPixels = 150000;
+
+// How a replayed step of B tiles of S x S is cut: two half-batch lanes (measured: profiles/r04_a_*, r04_y_*), one
 // whole-batch lane below.  A rule by the amount of work only; sub-batches start at even tiles so that kernels that pair images keep their pairs.
 static int lanes_for(const hd_ctx* c, int B, int S) {
     if (c->chains >= 0) return std::max(1, std::min(c->chains, B / 2));
-    return B >= 4 && (long long)B * S * S >= 524288 ? 2 : 1;
+    return B >= 4 && (long long)B * S * S >= kReplayMinPixels ? 2 : 1;
 }
 static int lane_start(int B, int n, int i) { return i >= n ? B : (int)(((long long)B * i / n + 1) & ~1LL); }      // first tile of lane i of n
 
@@ -1013,10 +1020,10 @@ static int run_step(hd_ctx* c, int kind, float* x, const float* aux, const float
                     int S, hipStream_t user) {
     if ((size_t)B * S * S > c->eps_cap) return fail(c, HD_ENOMEM, "workspace too small: call hd_reserve(ctx, B, S) first");
     // Replayed noise changes address every step and event profiling records per launch: both run eagerly.  So do small batches unless graphs are
-    // forced on: below ~256 k pixels per step the kernels are latency-bound and the eager launches of an idle host thread ran 6-10 % faster than
+    // forced on: below ~150 k pixels per step (kReplayMinPixels) the kernels are latency-bound and the eager launches of an idle host thread ran 6-10 % faster than
     // the replay (unet40: 4 tiles 2.23 vs 2.46 ms per step, 64 tiles 2.89 vs 3.08; profiles/r03_f_*), at full batches the two measure the same
     // (unet64, 256 tiles: 13.0-13.2 ms either way) and the replay keeps the step independent of what the host thread is doing.
-    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= 262144;
+    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= kReplayMinPixels;
     if (!graphs || noise != nullptr || hd_prof_is_on() || c->capture) {
         if (c->in_chain) HD_TRY(lanes_join(c, user));
         return step_body(c, kind, x, aux, noise, v, x0_out, B, S, user, nullptr);
@@ -1113,7 +1120,7 @@ int hd_set_chains(hd_ctx* c, int n) {
 
 int hd_chains_for(const hd_ctx* c, int B, int S) {
     if (!c || B < 1 || S < 1) return HD_EINVAL;
-    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= 262144;
+    const bool graphs = c->use_graphs >= 0 ? c->use_graphs != 0 : (long long)B * S * S >= kReplayMinPixels;
     return graphs ? lanes_for(c, B, S) : 1;
 }
 

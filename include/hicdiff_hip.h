@@ -185,7 +185,7 @@ int hd_fwht(float* data, int N, int L, float scale, void* stream);
  * (one per (B, S, tensor addresses); the per-step scalars travel through a 1-thread kernel) on a
  * stream owned by the context, ordered after/before the caller's stream by events.  0 disables it
  * (every kernel is then launched eagerly on the caller's stream), 1 forces it; untouched, a context replays steps of at least
- * 256 k pixels (B*S*S) and launches smaller ones eagerly (measured faster there); env HICDIFF_GRAPHS=0|1 forces either at hd_create. */
+ * 150 k pixels (B*S*S) and launches smaller ones eagerly (measured faster there); env HICDIFF_GRAPHS=0|1 forces either at hd_create. */
 int hd_set_graphs(hd_ctx* ctx, int enable);
 
 /* The loop of p_sample_loop (src/hicdiff.py:603-620; conditional src/hicdiff_condition.py:676-678; the DDRM loop
@@ -195,7 +195,7 @@ int hd_set_graphs(hd_ctx* ctx, int enable);
  * (replayed noise, a batch too small to replay) joins first, so mixing stays correct, only slower.  Large steps are cut into two
  * half-batch chains (tiles are independent for the whole chain) that advance side by side on two streams of the
  * context and only meet at hd_chain_end -- results are bit-identical to the single chain.  hd_set_chains(n): n = 1 never cuts,
- * n = 2..4 always cuts into n sub-batches, 0 restores the default (two from 512 k pixels per step on); env HICDIFF_CHAINS=n sets it at
+ * n = 2..4 always cuts into n sub-batches, 0 restores the default (two chains for every replayed step, i.e. from 150 k pixels per step on); env HICDIFF_CHAINS=n sets it at
  * hd_create.  hd_reserve / hd_set_chains inside a bracket return HD_ESTATE. */
 int hd_chain_begin(hd_ctx* ctx, void* stream);
 int hd_chain_end(hd_ctx* ctx, void* stream);

@@ -87,7 +87,7 @@ def precision(request, monkeypatch):
 
 @pytest.fixture(autouse=True)
 def _graphs_forced_on(monkeypatch):
-    """These tests are about the hipGraph replay of the fused steps.  Contexts replay by default only from 256 k pixels per step on (smaller
+    """These tests are about the hipGraph replay of the fused steps.  Contexts replay by default only from 150 k pixels per step on (smaller
     steps run faster eagerly: engine.hip run_step); the environment switch, read at hd_create, forces the replay for the small shapes used here."""
     monkeypatch.setenv("HICDIFF_GRAPHS", "1")
 
@@ -393,8 +393,8 @@ def test_chain_bracket_state_errors():
 
 @pytest.mark.parametrize("kind", ["uncond", "cond"])
 def test_two_chains_at_bench_batch_size_equal_the_single_chain(kind):
-    """bench.py's default workload as it now runs: 256 tiles of 64x64 as two 128-tile chains (the library's default rule from 512 k
-    pixels per step on), six steps inside a bracket, against the single 256-tile chain."""
+    """bench.py's default workload as it now runs: 256 tiles of 64x64 as two 128-tile chains (the library's default rule: every replayed
+    step), six steps inside a bracket, against the single 256-tile chain."""
     B, S, T = 256, 64, 1000
     net = product_unet(kind)
     d = diffusion_class(kind)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
