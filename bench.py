@@ -504,6 +504,9 @@ def main():
             "peak_note": ("algorithmic fp32-equivalent TFLOP/s; peak = dense bf16 / fp16 MFMA 2500 / MFMAs per product (3: split-bf16 x3; 2 / 1: the early "
                           "band's fp16 xh (wh + wl) / xh wh)" if split else "exact-fp32 MFMA peak"),
             "kernel": dom.kernel.decode(), "launches": int(dom.launches),
+            "launch_note": ("per-launch figures are HIP events around WHOLE-BATCH eager launches of the profiled steps (the kernel on its own, as with --chains 1: "
+                            "the rocprofv3 summary to compare with is profiles/*_chains1_kernel_stats.csv); the timed region replays the same kernels on "
+                            f"{chains} sub-batch chains whose launches overlap in a trace" if chains > 1 else "per-launch HIP events of the profiled eager steps"),
             "avg_launch_us": round(dom.total_ms * 1e3 / max(dom.launches, 1), 2),
             "conv_time_share": round(conv_ms * 1e-3 / (prof_steps * sec_per_step), 4),
             "all_convs_frac": round(sum(r.flops / peak_of(r.kernel) for r in rows) / max(conv_ms * 1e-3, 1e-12) / 1e12, 4),

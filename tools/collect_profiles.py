@@ -94,6 +94,9 @@ def main():
     os.makedirs(out, exist_ok=True)
     # --sustained-budget 0: the post-timing whole-chain run (1000 more steps) would only bloat the traces
     rocprof(os.path.join(work, "unet64"), ["--stats"], ["--sustained-budget", "0"], os.path.join(work, "unet64.log"))
+    # the same with ONE whole-batch chain: the launches bench.py's `roofline` describes (its per-launch events are recorded on eager whole-batch
+    # steps; the default run replays the kernels on two 128-tile halves whose durations overlap in the trace)
+    rocprof(os.path.join(work, "unet64_c1"), ["--stats"], ["--sustained-budget", "0", "--chains", "1", "--no-cpu-baseline"], os.path.join(work, "unet64_c1.log"))
     rocprof(os.path.join(work, "hicedrn64"), ["--stats"], ["--workload", "hicedrn64", "--steps", "5", "--warmup", "1", "--sustained-budget", "0"],
             os.path.join(work, "hicedrn64.log"))
     # counter passes: one whole-batch chain, so that a launch is the 256-tile launch the bench line's algorithmic bytes describe
@@ -106,6 +109,7 @@ def main():
         sq_reduce([os.path.join(work, "sqa", "p_counter_collection.csv"), os.path.join(work, "sqb", "p_counter_collection.csv")],
                   os.path.join(out, f"{tag}_unet64_b256_sq.json"),
                   "rocprofv3 --kernel-trace --pmc " + " ".join(SQ_A) + " | " + " ".join(SQ_B) + " (one pass each) -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --chains 1")
+    shutil.copy(os.path.join(work, "unet64_c1", "p_kernel_stats.csv"), os.path.join(out, f"{tag}_unet64_b256_chains1_kernel_stats.csv"))
     for wl in ("unet64", "hicedrn64"):
         shutil.copy(os.path.join(work, wl, "p_kernel_stats.csv"), os.path.join(out, f"{tag}_{wl}_b256_kernel_stats.csv"))
         with open(os.path.join(work, wl + ".log")) as f:
