@@ -406,7 +406,8 @@ def main():
     def spread(n):
         """n timesteps spread evenly over the chain, t = 999 first: since round 4 a step's cost depends on the HALF of the chain it sits in
         (the precision schedule), so K consecutive steps from t = 999 would time the cheaper half only.  The K-step
-        region is a stratified sample of the chain -- exactly the chain's mix for even K -- and `sustained` below is a whole chain."""
+        region is a stratified sample of the chain -- exactly the chain's mix of the three arithmetics when K is a multiple of 4 (the default 20 is) -- and
+        `sustained` below is a whole chain."""
         return [T_CHAIN - 1 - (i * T_CHAIN) // n for i in range(n)]
 
     # set-up, not warm-up: the step's hipGraphs are captured on the second call of each arithmetic (engine.hip lane_step)
