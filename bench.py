@@ -11,10 +11,11 @@
     python bench.py --gpus N --workload hicedrn64 --total-tiles 256      (strong-scaling form of BASELINE configs[3]: 256/N tiles per GPU)
 
 A "step" is one pass of the hot path over one batch: the epsilon-network forward plus the fused
-posterior update for B tiles (one hd_ddpm_step call).  Since round 4 a step's cost depends on the half of the
-chain it sits in (the precision schedule: two fp16 products in the 3x3 convolutions for t >= T/2, DESIGN.md
-section 4e), so the K timed steps are spread evenly over the chain (t = 999, 999 - 1000/K, ...): a stratified
-sample whose mean is the chain's mean for even K; tiles/s = tiles per batch / (1000 * mean seconds per step).
+posterior update for B tiles (one hd_ddpm_step call).  Since round 4 a step's cost depends on the part of the
+chain it sits in (the precision schedule of the 3x3 convolutions: one fp16 product for t >= 3T/4, two for
+t >= T/2, two on the low-resolution maps only below that), so the K timed steps are spread
+evenly over the chain (t = 999, 999 - 1000/K, ...): a stratified sample whose mean is the chain's mean when K is a
+multiple of 4 (the default 20); tiles/s = tiles per batch / (1000 * mean seconds per step).
 The line also carries `sustained`: a whole 1000-step chain (or as much of one as fits the time budget) timed
 after the K-step region.  Tiles shard across ranks with no data-path collective (weak scaling: B tiles per
 GPU); the one RCCL all-gather of the finished tiles is exercised after the timed region and reported
