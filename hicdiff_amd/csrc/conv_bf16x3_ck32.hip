@@ -60,7 +60,13 @@ static int launch_mode(ConvLaunch& L, hipStream_t st) {
     hd_set_error("conv: no bf16x3 kernel variant for this tile"); return -1;
 }
 
+int launch_conv_bf16_plain_ck32(ConvLaunch& L, hipStream_t st);   // conv_bf16_plain_ck32.hip: 1 = no plain-bf16 form of this launch
+
 int launch_conv_bf16x3_ck32(ConvLaunch& L, hipStream_t st) {
+    if (L.k.plain && L.cfg <= 2) {
+        const int rc = launch_conv_bf16_plain_ck32(L, st);
+        if (rc != 1) return rc;
+    }
     switch (conv_kernel_mode(L)) {
         case IN_AFFINE_SILU: return launch_mode<IN_AFFINE_SILU>(L, st);
         case IN_AFFINE_SILU_E: return launch_mode<IN_AFFINE_SILU_E>(L, st);

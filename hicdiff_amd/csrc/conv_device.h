@@ -49,7 +49,7 @@ struct ConvKArgs {
     unsigned long long split_stride;   // floats between the splits' partial outputs (out then points at the workspace)
     int m16;      // bf16x3 kernel family: 1 = the launch runs on 16 x 16 MFMA tiles (row -> pixel maps are laid out for 16-row operand blocks)
     int f16w2;    // bf16x3 kernel family, 3x3 kernels: 1 = two fp16 products per multiply, xh (wh + wl); 2 = one, xh wh; wsplit then points at the fp16 image
-    int plain;    // bf16x3 kernel family: 1 = one bf16 MFMA per product (training's optional bf16 arithmetic; 8-wave 3x3 variant only)
+    int plain;    // bf16x3 kernel family: 1 = one bf16 MFMA per product (training's optional bf16 arithmetic: 32-channel-slice kernels, plain / GroupNorm-apply loaders)
 #ifdef HD_STAMPS
     unsigned long long* stamps;   // timing study builds only (make EXTRA=-DHD_STAMPS): [4096][16] cycle stamps, see conv_bf16x3_kernel.h
 #endif

@@ -1307,6 +1307,7 @@ int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int
         if (hipMalloc(&psplit, (size_t)KH * KH * Cin * cw.CoutPad * 2 * sizeof(unsigned short)) != hipSuccess) { (void)hipFree(pw); return HD_EHIP; }
         rc = launch_split_conv(cw.w, (unsigned short*)psplit, KH * KH, Cin, cw.CoutPad, 16, st);
         a.cw.wsplit = (unsigned short*)psplit; a.cw.ck = cw.ck; a.precision = HD_PREC_BF16X3;
+        if (mode & 2048) a.plain_bf16 = 1;     // ONE bf16 product (the training step's optional arithmetic), where the kernel form exists
     }
     void* psplit16 = nullptr;
     if ((mode & 512) && (mode & 32) && rc == 0) {          // two fp16 products per multiply (3x3 only; launch_conv falls back to x3 where it does not apply)

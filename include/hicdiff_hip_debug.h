@@ -17,7 +17,9 @@ extern "C" {
  *   A,Bv [B][Cin] (E optional), 16 = LayerNorm input transform (stats computed internally, g = A),
  *   32 = split-bf16 x3 arithmetic instead of exact fp32, 64 = use the 32-channel K slice, 128 = LayerNorm statistics passed in Bv,
  *   256 (with 32; 3x3 only) = also pack the Winograd F(2x2,3x3) filter image, so the convolution runs on conv_winograd.hip -- an
- *   error if the shape is not one that kernel takes; 512 (with 32; 3x3 only) = two fp16 products per multiply, xh (wh + wl); 1024 (with 512) = one, xh wh. */
+ *   error if the shape is not one that kernel takes; 512 (with 32; 3x3 only) = two fp16 products per multiply, xh (wh + wl); 1024 (with 512) = one, xh wh;
+ *   2048 (with 32 | 64) = ONE bf16 product per multiply (the training step's optional arithmetic; 32-channel slices, plain / GroupNorm-apply loaders --
+ *   three products where that kernel form does not exist). */
 int hd_debug_conv(const float* in0, int C0, const float* in1, int C1, int B, int IH, int IW, const float* w,
                   const float* bias, int Cout, int K, int mode, const float* A, const float* Bv, const float* E,
                   float* out, void* stream);

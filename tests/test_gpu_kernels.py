@@ -503,6 +503,33 @@ def test_conv3x3_one_fp16_product(B, S, Cin, Cout):
     assert torch.equal(got, run_conv(x, None, w, b, 3, 1024 | 512 | 96))
 
 
+@pytest.mark.parametrize("B,S,Cin,Cout,K", [(2, 16, 128, 128, 3), (1, 64, 64, 64, 3), (3, 8, 128, 256, 3), (2, 32, 128, 64, 3), (2, 40, 256, 256, 3),
+                                            (2, 16, 128, 128, 1), (1, 64, 128, 64, 1), (3, 8, 256, 64, 1)])
+def test_conv_one_bf16_product(B, S, Cin, Cout, K):
+    """AR = 1, the training step's optional arithmetic on every 32-channel-slice tile shape (conv_bf16_plain_ck32.hip + the 8-wave form):
+    against torch conv2d of the bf16-rounded activations AND bf16-rounded weights (what the mode is defined as)."""
+    x, w, b = rnd(1, B, Cin, S, S), rnd(2, Cout, Cin, K, K) / (K * Cin ** 0.5), rnd(3, Cout)
+    got = run_conv(x, None, w, b, K, 2048 | 96)
+    r = lambda t: t.bfloat16().float()
+    assert rel_err(F.conv2d(r(x), r(w), b, padding=K // 2), got) < 1e-4
+    assert 1e-4 < rel_err(F.conv2d(x, w, b, padding=K // 2), got) < 2e-2          # it really is the cheaper arithmetic
+    assert torch.equal(got, run_conv(x, None, w, b, K, 2048 | 96))
+
+
+def test_conv_one_bf16_product_groupnorm_apply_loader():
+    """... with the GroupNorm-apply + SiLU loader (+ the time-embedding term), two sources: the transformed activation is what gets rounded."""
+    B, S = 2, 16
+    x0, x1 = rnd(1, B, 64, S, S), rnd(2, B, 64, S, S)
+    w, b = rnd(3, 128, 128, 3, 3) / (3 * 128 ** 0.5), rnd(4, 128)
+    A, Bv = rnd(5, B, 128) * 0.5 + 1, rnd(6, B, 128) * 0.3
+    x = torch.cat((x0, x1), 1)
+    xt = F.silu(x * A[:, :, None, None] + Bv[:, :, None, None])
+    got = run_conv(x0, x1, w, b, 3, 2048 | 96 | 8, A=A, Bv=Bv)
+    r = lambda t: t.bfloat16().float()
+    assert rel_err(F.conv2d(r(xt), r(w), b, padding=1), got) < 2e-3              # (the loader's SiLU uses the hardware exp: roundings to bf16 can flip)
+    assert rel_err(F.conv2d(xt, w, b, padding=1), got) < 2e-2
+
+
 def test_conv3x3_two_fp16_products_loaders_and_geometry():
     """GroupNorm-apply + SiLU loader (rounding happens AFTER the transform), concat of two sources, nearest-x2 upsample."""
     B, Cc, S = 3, 64, 32

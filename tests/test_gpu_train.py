@@ -730,6 +730,37 @@ def test_unet_train_gradients_vs_autograd_oracle(kind, dim, mults, B, S):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:12]
 
 
+def test_unet_train_plain_bf16_option():
+    """The UNet's step under the optional bf16 arithmetic (one bf16 MFMA per product in every 32-channel-slice convolution -- forward and data
+    gradient -- and in the weight-gradient GEMMs; fp32 master weights, accumulation, normalisations and attention): loss within 1e-2, every
+    gradient tensor within 5e-2 of its largest fp32 entry, and the step repeats bit for bit."""
+    from oracle import diffusion as OD, nets as ON, train as OTR, weights as W
+    kind, dim, mults, B, S = "cond", 64, (1, 2, 4, 8), 2, 40
+    d = _unet_diffusion(kind, dim, mults, S)
+    d.model.train_precision = "bf16"
+    d.train()
+    cfg = ON.UnetCfg(dim=dim, dim_mults=tuple(mults), self_condition=True, sr3=False)
+    sd = W.fill_state_dict(W.unet_shapes(dim=dim, dim_mults=tuple(mults), self_condition=True, sr3=False))
+    x0, lq = tiles(51, B, S), tiles(52, B, S)
+    gen = torch.Generator().manual_seed(7)
+    t, eps = torch.randint(0, 1000, (B,), generator=gen), torch.randn(x0.shape, generator=gen)
+    ol, og = OTR.loss_and_grads(sd, cfg, OD.diffusion_buffers("linear", 1000), x0, t, eps, lq, "l2")
+    val = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
+    val.backward()
+    assert d.model.__dict__["_hd_trainer"].precision == "bf16"
+    assert abs(float(val.detach()) - float(ol)) <= 1e-2 * float(ol)
+    errs = {k: rel_err(og[k], p.grad) for k, p in d.model.named_parameters()}
+    print(f"unet bf16 option: loss {float(val.detach()):.6f} vs {float(ol):.6f}; gradient errors max {max(errs.values()):.2e}, median {sorted(errs.values())[len(errs) // 2]:.2e}")
+    assert max(errs.values()) <= 5e-2, max(errs.items(), key=lambda kv: kv[1])
+    assert max(errs.values()) > 1e-3                        # it really is the cheaper arithmetic
+    first = {k: p.grad.clone() for k, p in d.model.named_parameters()}
+    for p in d.model.parameters():
+        p.grad = None
+    val2 = _loss(d, kind, lq.cuda(), x0.cuda(), t.cuda(), eps.cuda())
+    val2.backward()
+    assert torch.equal(val, val2) and all(torch.equal(first[k], p.grad) for k, p in d.model.named_parameters())
+
+
 @pytest.mark.parametrize("kind", ["cond", "uncond", "sr3"])
 def test_unet_train_two_steps_golden(kind):
     """Two steps of loss.backward() + Adam(lr=2e-5) on the two-level UNet the reference ran (make_golden.py::case_train_unet)."""

@@ -31,11 +31,11 @@ def _asm(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src", ["conv_bf16x3_ck16.hip", "conv_bf16x3_ck32.hip"])
+@pytest.mark.parametrize("src", ["conv_bf16x3_ck16.hip", "conv_bf16x3_ck32.hip", "conv_bf16_plain_ck32.hip"])
 def test_conv_kernels_have_no_scratch_and_no_odd_register_broadcast(src):
     text = _asm(src)
     kernels = re.findall(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, flags=re.S)
-    assert len(kernels) >= 20
+    assert len(kernels) >= (20 if "x3" in src else 9)
     for name, body in kernels:
         m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", body)
         assert m and int(m.group(1)) == 0, f"{name} uses {m.group(1) if m else '?'} bytes of scratch per lane"
