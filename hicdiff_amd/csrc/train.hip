@@ -1070,12 +1070,22 @@ __global__ __launch_bounds__(256) void small_conv_wgrad_kernel(const float* __re
                 acc[i] = 0.f;
                 off[i] = (j * LH + R + sign * (t / KS - R)) * LW + R + sign * (t % KS - R);
             }
+            // eight pixels' values requested together: one load per pixel in flight at a time made this a chain of exposed HBM round trips
+            // (the UNet's first convolution: 324 us for 67 MB).  Same summation order as the scalar loop.
             for (int yy = 0; yy < RB && y0 + yy < S; ++yy)
-                for (int x = 0; x < S; ++x) {
-                    const float v = big[(((size_t)b * S + y0 + yy) * S + x) * C + c];
-                    const float* row = sm + yy * LW + x;
+                for (int x0 = 0; x0 < S; x0 += 8) {
+                    const float* src = big + (((size_t)b * S + y0 + yy) * S + x0) * C + c;
+                    float v[8];
 #pragma unroll
-                    for (int i = 0; i < TP; ++i) acc[i] += v * row[off[i]];
+                    for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(u, S - 1 - x0) * C];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        if (x0 + u < S) {
+                            const float* row = sm + yy * LW + x0 + u;
+#pragma unroll
+                            for (int i = 0; i < TP; ++i) acc[i] += v[u] * row[off[i]];
+                        }
+                    }
                 }
             float* d = part + ((size_t)(b * nrb + rb) * C + c) * (J * T) + j * T;
 #pragma unroll
