@@ -327,7 +327,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st, int* gn_slots_out) {
     k.ksplit = 1; k.kchunks = 0; k.split_stride = 0;
     k.plain = a.plain_bf16;
     // two fp16 products per multiply: 3x3 layers that carry the fp16 image, shared weights, none of the training-only forms
-    const bool f16ok = a.f16w2 && a.cw.wsplit16 && a.cw.KH == 3 && a.cw.KW == 3 && !a.w_bstride && !a.plain_bf16 && !(a.ep & EP_FILM_SILU_BWD) &&
+    const bool f16ok = a.f16w2 && a.cw.wsplit16 && a.cw.f16_range_ok && a.cw.KH == 3 && a.cw.KW == 3 && !a.w_bstride && !a.plain_bf16 && !(a.ep & EP_FILM_SILU_BWD) &&
               a.in_mode != IN_LAYERNORM && a.in_mode != IN_SOFTMAX32 && !(a.in_mode == IN_AFFINE_SILU && a.inE) && a.precision == HD_PREC_BF16X3;
     k.f16w2 = f16ok ? (a.f16w2 >= 2 ? 2 : 1) : 0;             // 1: xh (wh + wl), 2: xh wh
     // (the SR3 blocks' loader with the additive term keeps three products: its 256 x 64 instantiation does not fit the registers without scratch)
@@ -456,9 +456,15 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict_
 // f16 != 0: fp16 hi | lo instead (the two-product arithmetic's image: hi = fp16(w), lo = fp16(w - hi), subnormals kept -- the fp16 MFMAs
 // honour them, tools/mfma_f16_denorm_probe.hip).
 __global__ __launch_bounds__(256) void split_conv_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int taps,
-                                                         int Cin, int CoutPad, int CK, int f16) {
+                                                         int Cin, int CoutPad, int CK, int f16, unsigned* __restrict__ absmax) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t total = (size_t)taps * Cin * CoutPad;
+    if (absmax) {                                        // largest |w| of the layer (non-negative floats order as their bit patterns)
+        unsigned m = i < total ? __builtin_bit_cast(unsigned, fabsf(w[i])) : 0u;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, s, 64));
+        if ((threadIdx.x & 63) == 0 && m) atomicMax(absmax, m);
+    }
     if (i >= total) return;
     const int n = (int)(i % CoutPad);
     const int cin = (int)((i / CoutPad) % Cin);
@@ -488,9 +494,9 @@ int launch_pack_conv(const float* src, float* dst, int Cout, int Cin, int KH, in
     return 0;
 }
 
-int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16) {
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16, unsigned* absmax) {
     const size_t total = (size_t)taps * Cin * CoutPad;
-    hipLaunchKernelGGL(split_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, dst, taps, Cin, CoutPad, CK, f16);
+    hipLaunchKernelGGL(split_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, packed, dst, taps, Cin, CoutPad, CK, f16, f16 ? absmax : nullptr);
     return 0;
 }
 

@@ -139,6 +139,7 @@ struct hd_ctx {
     int use_graphs = -1;           // 1 / 0: always / never replay the fused steps from a hipGraph; -1 (default): by the amount of work, see run_step
     int chains = -1;               // n >= 1: always cut a replayed step into n sub-batch lanes (1: never); -1 (default): by the amount of work, see lanes_for
     int lane_delay_us = 0;         // experiment knob (HICDIFF_LANE_DELAY_US): lane 1 starts a chain this much later than lane 0
+    unsigned* f16_absmax = nullptr;   // device slots of the loader's fp16 range guard (one per 3x3 layer)
     bool in_chain = false;         // between hd_chain_begin and hd_chain_end
     bool forked = false;           // in_chain: the lanes already wait behind the caller's stream
     // test-only capture of intermediates (hicdiff_hip_debug.h)
@@ -157,6 +158,41 @@ static int keep_err(hd_ctx* c, int rc) { if (rc != 0 && c) c->err = g_err; retur
 struct Loader {
     hd_ctx* c; hipStream_t st;
     std::unordered_map<std::string, const hd_named_tensor*> map;
+    // Range guard of the fp16 weight images (the schedule's two- and one-product arithmetic): hi = fp16(w), lo = fp16(w - hi) is exact to ~2^-25
+    // ABSOLUTE (fp16 subnormals), so a layer whose largest weight is below 2^-8 would carry less than the 2^-17 relative accuracy the error budget
+    //  assumes, and one above 2^15 would overflow hi.  Such a layer keeps three bf16 products at every step.  The packed
+    // weights are what is measured (after weight standardisation where the layer has it), one atomicMax slot per layer, read back once per load.
+    std::vector<ConvW*> f16_layers;
+    static constexpr int kF16Slots = 1024;
+    int f16_slot(ConvW* w, unsigned** slot) {
+        if (!c->f16_absmax) {
+            if (hipMalloc((void**)&c->f16_absmax, kF16Slots * sizeof(unsigned)) != hipSuccess) return fail(c, HD_EHIP, "hipMalloc(weights) failed");
+            c->owned.push_back(c->f16_absmax);
+        }
+        if (f16_layers.empty() && hipMemsetAsync(c->f16_absmax, 0, kF16Slots * sizeof(unsigned), st) != hipSuccess) return fail(c, HD_EHIP, "weight range memset failed");
+        if ((int)f16_layers.size() >= kF16Slots) { *slot = nullptr; return 0; }       // (no network here has that many layers: unguarded beyond)
+        *slot = c->f16_absmax + f16_layers.size();
+        f16_layers.push_back(w);
+        return 0;
+    }
+    int finish_f16_range() {
+        if (f16_layers.empty()) return 0;
+        std::vector<unsigned> bits(f16_layers.size());
+        if (hipMemcpyAsync(bits.data(), c->f16_absmax, bits.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(c, HD_EHIP, "weight range readback failed");
+        bool changed = false;
+        for (size_t i = 0; i < bits.size(); ++i) {
+            const float m = __builtin_bit_cast(float, bits[i]);
+            const int ok = m >= 0.00390625f && m <= 32768.f ? 1 : 0;              // (NaN / inf weights fail both)
+            changed |= ok != f16_layers[i]->f16_range_ok;
+            f16_layers[i]->f16_range_ok = ok;
+        }
+        if (changed) {                                                              // a captured step holds the kernel choice
+            if (hipDeviceSynchronize() != hipSuccess) return fail(c, HD_EHIP, "device synchronize failed");
+            for (auto& ln : c->lane) ln.drop_graphs();
+        }
+        return 0;
+    }
     const hd_named_tensor* get(const std::string& name, std::initializer_list<int64_t> shape) {
         auto it = map.find(name);
         if (it == map.end()) { fail(c, HD_ENOWEIGHT, "missing state-dict entry '" + name + "'"); return nullptr; }
@@ -206,7 +242,9 @@ struct Loader {
                 c->owned.push_back(p);
                 w->wsplit16 = (unsigned short*)p;
             }
-            HD_TRY(launch_split_conv(w->w, w->wsplit16, 9, cin, w->CoutPad, 16, st, 1));
+            unsigned* slot = nullptr;
+            HD_TRY(f16_slot(w, &slot));
+            HD_TRY(launch_split_conv(w->w, w->wsplit16, 9, cin, w->CoutPad, 16, st, 1, slot));
         }
         // Winograd image of the 3x3 filters (conv_winograd.hip): only while that opt-in path is switched on (HICDIFF_WINOGRAD=1 / hd_debug_winograd(1)
         // before the weights are loaded) -- the image is 16/9 of the filter bytes twice over and one more pack launch per layer; without it
@@ -846,6 +884,7 @@ int hd_load_weights(hd_ctx* c, const hd_named_tensor* tensors, int n, void* stre
     Loader L{c, (hipStream_t)stream, {}};
     for (int i = 0; i < n; ++i) L.map[tensors[i].name] = &tensors[i];
     int rc = c->arch.kind == HD_ARCH_UNET ? load_unet(L) : load_hicedrn(L);
+    if (rc == 0) rc = L.finish_f16_range();
     if (rc == 0) c->loaded = true;
     // the allocation plan follows what was loaded (which attention blocks have fused weight images): a workspace reserved before the
     // first load is re-sized for the plan as it is now (grow-only; a no-op in the usual order, load then reserve)

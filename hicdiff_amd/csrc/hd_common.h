@@ -23,6 +23,7 @@ struct ConvW {
     unsigned short* wino = nullptr;     // 3x3 only: Winograd F(2x2,3x3) filter transform, split bf16, MFMA-fragment order (conv_winograd.hip)
     float* bias = nullptr;
     int KH = 1, KW = 1, Cin = 0, Cout = 0, CoutPad = 0, ck = 16;   // ck: activation slice of the bf16x3 kernel (32 where the channel counts allow)
+    int f16_range_ok = 1;             // the fp16 hi | lo image is faithful: max |w| inside [2^-8, 2^15] (engine.hip Loader::finish_f16_range); else the layer keeps three products
 };
 
 enum { HD_PREC_F32 = 0, HD_PREC_BF16X3 = 1 };
@@ -135,7 +136,7 @@ int conv_gn_slots(const ConvArgs& a);  // slots per sample the fused GN partials
 
 int launch_pack_conv(const float* src_oihw, float* dst, int Cout, int Cin, int KH, int KW, int CoutPad,
                      int standardize, int unshuffle, hipStream_t st);
-int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16 = 0);
+int launch_split_conv(const float* packed, unsigned short* dst, int taps, int Cin, int CoutPad, int CK, hipStream_t st, int f16 = 0, unsigned* absmax = nullptr);   // absmax (f16 only): atomicMax of the bits of |w| over the filter
 size_t conv_winograd_weight_bytes(int Cin, int CoutPad);
 int launch_pack_winograd(const float* packed, unsigned short* dst, int Cin, int CoutPad, hipStream_t st);   // packed: fp32 [9][Cin][CoutPad]
 bool conv_uses_winograd(const ConvArgs& a);   // a.precision must be set

@@ -100,7 +100,9 @@ typedef struct {
     uint32_t arith;                      /* arithmetic of THIS step's 3x3 convolutions: HD_ARITH_DEFAULT (the context's, hd_set_precision) or
                                             HD_ARITH_F16W2 / HD_ARITH_F16W1 (two / one fp16 products per multiply, xh (wh + wl) / xh wh; only on a
                                             context in HD_PRECISION_BF16X3).  The host's
-                                            precision schedule over a chain: hicdiff_amd/_diffusion.py, DESIGN.md section 4e */
+                                            precision schedule over a chain: hicdiff_amd/_diffusion.py, DESIGN.md section 4e.
+                                            A layer whose largest packed weight lies outside [2^-8, 2^15] (measured by hd_load_weights)
+                                            keeps three bf16 products whatever is asked: its fp16 hi | lo image would not be faithful. */
 } hd_ddpm_coef;
 enum { HD_ARITH_DEFAULT = 0, HD_ARITH_F16W2 = 1, HD_ARITH_F16W1 = 2,
        HD_ARITH_F16W2_LOW = 3 /* two fp16 products on the feature maps of at most (S/4)^2 pixels, three elsewhere */ };

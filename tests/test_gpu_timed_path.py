@@ -623,6 +623,43 @@ def test_two_product_forward_vs_oracle(kind):
     assert 1e-5 < rel_err(want, got1) < 6e-3 and not torch.equal(got, got1)          # one fp16 product: the weights are rounded as well
 
 
+def test_fp16_weight_image_range_guard():
+    """The loader measures max |w| of every 3x3 layer's packed weights; a layer outside [2^-8, 2^15] -- where fp16 hi | lo (exact to ~2^-25
+    absolute) would no longer carry the weight to the accuracy the error budget assumes -- keeps three bf16 products under every arithmetic
+    (engine.hip Loader::finish_f16_range).  hicedrn's convolutions are plain nn.Conv2d: scaled by 2^-12 (exact) they fall under the guard and
+    the one-product mode must give the x3 result bit for bit; unscaled, the cheaper arithmetic is visible.  Reloading flips the guard back."""
+    from _util import product_hicedrn
+    from hicdiff_amd import _lib as L
+    m = product_hicedrn("uncond", 3)
+    x, t = tiles(5, 4, 40).cuda(), torch.tensor([900, 500, 100, 3], device="cuda")
+
+    def both():
+        out = []
+        for prec in (L.HD_PRECISION_BF16X3, L.HD_PRECISION_F16W1):
+            eng = _eng(m)                      # (syncs the weights: the parameters' version counters moved)
+            eng.set_precision(prec)
+            try:
+                out.append(m(x, t).clone())
+            finally:
+                eng.set_precision(L.HD_PRECISION_BF16X3)
+        return out
+
+    a3, a1 = both()
+    assert not torch.equal(a3, a1) and rel_err(a3.cpu(), a1) < 6e-3
+    wide = [p for p in m.parameters() if p.ndim == 4 and p.shape[-1] == 3 and p.shape[1] % 16 == 0]
+    assert len(wide) >= 4
+    with torch.no_grad():
+        for p in wide:
+            p.mul_(2.0 ** -12)
+    b3, b1 = both()
+    assert torch.equal(b3, b1)
+    with torch.no_grad():
+        for p in wide:
+            p.mul_(2.0 ** 12)
+    c3, c1 = both()
+    assert torch.equal(c3, a3) and torch.equal(c1, a1)
+
+
 def test_precision_schedule_added_error_at_bench_batch(capsys):
     """BASELINE's headline workload as `bench.py` runs it -- 256 tiles of 64x64, T = 1000, two half-batch chains, the default precision schedule
     (one / two fp16 products in the early band, two on the low-resolution layers below it) -- against the same chain with split-bf16 x3 at
