@@ -95,6 +95,7 @@ class DiffusionCore(nn.Module):
         self.loss_type = loss_type
 
         betas = _SCHEDULES[beta_schedule](timesteps, **schedule_fn_kwargs)
+        self.__dict__["_beta_schedule_name"] = beta_schedule          # the precision schedule is measured per beta schedule (_early_band)
         alphas = 1. - betas
         ac = torch.cumprod(alphas, dim=0)
         ac_prev = F.pad(ac[:-1], (1, 0), value=1.)
@@ -248,10 +249,18 @@ class DiffusionCore(nn.Module):
 
     def _early_band(self, t_idx: int) -> bool:
         """Does step t take the two-product arithmetic?  Long chains only (the 50-step chains amplify a per-step error 4-7 x more: each of
-        their steps is twenty steps' worth of posterior_mean_coef1), their first half only, and networks that declare EARLY_BAND_OK (the UNet: what
-        the CPU study and the GPU drift runs covered)."""
+        their steps is twenty steps' worth of posterior_mean_coef1), their first half only, networks that declare EARLY_BAND_OK (what the CPU
+        study and the GPU drift runs covered) -- and the LINEAR beta schedule only (EARLY_BAND_SCHEDULES): what a chain forgives depends on how
+        long it stays at low noise.  The same bands on the reference's default sigmoid schedule (alphas_cumprod 0.50 at T/2 against the linear
+        schedule's 0.078) and on the cosine one ended 1.0-2.4e-3 from the x3 chain, and bands moved to where those chains are as noisy as
+        the linear one (t >= 835 / 989 of 1000) with two products on the low-resolution layers below still 0.3-1.9e-3: half of a sigmoid
+        chain runs at alphas_cumprod > 0.5, where nothing damps an error, against a sixth of a linear one (profiles/r04_s_*).  Other
+        schedules keep split-bf16 x3 at every step (1.0-1.9e-4 from the oracle on the same chains)."""
         T = self.num_timesteps
-        return bool(self.early_band_f16) and T >= 500 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
+        return (bool(self.early_band_f16) and T >= 500 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
+                and self.__dict__.get("_beta_schedule_name") in self.EARLY_BAND_SCHEDULES)
+
+    EARLY_BAND_SCHEDULES = ("linear",)     # beta schedules the precision schedule has been measured on (train.py's; BASELINE's bench configuration)
 
     def _band_from(self) -> float:
         return float(getattr(self.model, "EARLY_BAND_FROM", 0.5) if self.early_band_from is None else self.early_band_from)

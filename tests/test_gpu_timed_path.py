@@ -598,6 +598,15 @@ def test_early_band_schedule_is_what_the_long_chain_runs_and_nothing_else():
     b, _ = d.p_sample(x, 900)
     b2, _ = d.p_sample(x, 600)
     assert not torch.equal(a, b) and rel_err(b, a) < 1e-3 and not torch.equal(a2, b2) and rel_err(b2, a2) < 1e-3
+    # the schedule was measured on the LINEAR beta schedule; the reference's default sigmoid and the cosine schedule stay at low noise far longer
+    # and the same bands cost them 1.0-2.4e-3 (profiles/r04_s_*): they keep three products at every step, switch or no switch
+    for sched in ("sigmoid", "cosine"):
+        ds = diffusion_class("uncond")(product_unet("uncond", 16, (1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule=sched).cuda()
+        assert ds.early_band_f16 and {ds._coef(t).arith for t in (999, 900, 600, 100, 0)} == {L.HD_ARITH_DEFAULT}
+        on, _ = ds.p_sample(x, 900)
+        ds.early_band_f16 = False
+        off, _ = ds.p_sample(x, 900)
+        assert torch.equal(on, off)
 
 
 @pytest.mark.parametrize("kind", ["uncond", "cond", "sr3"])

@@ -421,5 +421,12 @@ def test_precision_schedule_policy_on_the_host():
     assert [h._coef(t).arith for t in (999, 749, 0)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2]   # hicedrn: the whole chain
     h.early_band_from = 0.5
     assert h._coef(0).arith == L.HD_ARITH_F16W2_LOW and h._coef(500).arith == L.HD_ARITH_F16W2
+    # measured on the linear beta schedule only: the reference's default (sigmoid) and cosine keep three products at every step
+    # (the linear bands cost them 1.0-2.4e-3: profiles/r04_s_*)
+    for sched in ("sigmoid", "cosine"):
+        g = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule=sched)
+        assert {g._coef(t).arith for t in range(0, 1000, 7)} == {L.HD_ARITH_DEFAULT}, sched
+    sr3_like = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=2000, loss_type="l2", beta_schedule="linear")
+    assert [sr3_like._coef(t).arith for t in (1999, 1500, 1499, 1000, 999)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2_LOW]
     import ctypes as C
     assert C.sizeof(L.HdDdpmCoef) == 36 and C.sizeof(L.HdDdrmCoef) == 44                          # include/hicdiff_hip.h

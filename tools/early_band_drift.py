@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--fracs", type=float, nargs="+", default=[1.0, 0.5, 0.25, 0.0])
     ap.add_argument("--cases", nargs="*", default=["uncond:40", "cond:64"])
     ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--schedule", default="linear", choices=["linear", "cosine", "sigmoid"], help="beta schedule of the chains (the reference's class default and inference.py: sigmoid; train.py and bench.py: linear)")
     ap.add_argument("--late-low", action="store_true", help="below the band: two fp16 products on the maps of at most (S/4)^2 pixels")
     ap.add_argument("--x1-from", type=float, default=0.75, help="inside the band, steps t >= this fraction of T take ONE fp16 product (2: never)")
     ap.add_argument("--vs-gpu", nargs="*", default=[], help="cases (e.g. hicedrn:40 hicedrn:64 uncond:64) measured against the GPU's own split-bf16 x3 chain "
@@ -38,11 +39,11 @@ def main():
     for case in a.cases:
         kind, S = case.split(":")[0], int(case.split(":")[1])
         net, ref_net = product_unet(kind), oracle_unet(kind)
-        d = diffusion_class(kind)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+        d = diffusion_class(kind)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule=a.schedule).cuda()
         d.early_band_x1_from, d.late_band_low_f16 = a.x1_from, a.late_low
         for seed in a.seeds:
             lq = tiles(seed, B, S) if kind != "uncond" else None
-            ref = OD.DiffusionRef(ref_net, image_size=S, timesteps=T, beta_schedule="linear", loss_type="l2", kind=kind)
+            ref = OD.DiffusionRef(ref_net, image_size=S, timesteps=T, beta_schedule=a.schedule, loss_type="l2", kind=kind)
             t0 = time.time()
             want = ref.p_sample_loop(lq if lq is not None else (B, 1, S, S), AncestralDeviceNoise(B, S, T, seed))
             line = f"{kind:6s} {S}x{S} seed {seed:5d} (oracle {time.time() - t0:4.0f} s):"
@@ -60,7 +61,7 @@ def vs_gpu(a):
         net = product_hicedrn("uncond", 32) if kind == "hicedrn" else product_unet(kind)
         net.EARLY_BAND_OK = True
         flavour = "uncond" if kind == "hicedrn" else kind
-        d = diffusion_class(flavour)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule="linear").cuda()
+        d = diffusion_class(flavour)(net, image_size=S, timesteps=T, loss_type="l2", beta_schedule=a.schedule).cuda()
         d.early_band_x1_from, d.late_band_low_f16 = a.x1_from, a.late_low
         B = a.batch
         for seed in a.seeds:
