@@ -255,10 +255,12 @@ class DiffusionCore(nn.Module):
         schedule's 0.078) and on the cosine one ended 1.0-2.4e-3 from the x3 chain, and bands moved to where those chains are as noisy as
         the linear one (t >= 835 / 989 of 1000) with two products on the low-resolution layers below still 0.3-1.9e-3: half of a sigmoid
         chain runs at alphas_cumprod > 0.5, where nothing damps an error, against a sixth of a linear one (profiles/r04_s_*).  Other
-        schedules keep split-bf16 x3 at every step (1.0-1.9e-4 from the oracle on the same chains)."""
+        schedules keep split-bf16 x3 at every step (1.0-1.9e-4 from the oracle on the same chains).  And the pred_noise objective only -- the
+        reference's, and the one measured: with pred_x0 / pred_v the network's error reaches x0 with gain 1 instead of
+        sqrt_recipm1_alphas_cumprod[t], which is 0.01 at the end of a chain, exactly where the late tier would put it."""
         T = self.num_timesteps
         return (bool(self.early_band_f16) and T >= 500 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
-                and self.__dict__.get("_beta_schedule_name") in self.EARLY_BAND_SCHEDULES)
+                and self.__dict__.get("_beta_schedule_name") in self.EARLY_BAND_SCHEDULES and self.objective == "pred_noise")
 
     EARLY_BAND_SCHEDULES = ("linear",)     # beta schedules the precision schedule has been measured on (train.py's; BASELINE's bench configuration)
 

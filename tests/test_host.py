@@ -426,6 +426,9 @@ def test_precision_schedule_policy_on_the_host():
     for sched in ("sigmoid", "cosine"):
         g = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule=sched)
         assert {g._coef(t).arith for t in range(0, 1000, 7)} == {L.HD_ARITH_DEFAULT}, sched
+    for obj in ("pred_x0", "pred_v"):           # measured for the reference's objective only
+        g = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=1000, loss_type="l2", beta_schedule="linear", objective=obj)
+        assert {g._coef(t).arith for t in (999, 600, 100, 0)} == {L.HD_ARITH_DEFAULT}, obj
     sr3_like = GaussianDiffusion(Unet(16, dim_mults=(1, 2)), image_size=16, timesteps=2000, loss_type="l2", beta_schedule="linear")
     assert [sr3_like._coef(t).arith for t in (1999, 1500, 1499, 1000, 999)] == [L.HD_ARITH_F16W1, L.HD_ARITH_F16W1, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2, L.HD_ARITH_F16W2_LOW]
     import ctypes as C
