@@ -132,7 +132,7 @@ class DiffusionCore(nn.Module):
         self.unnormalize = (lambda t: (t + 1) * 0.5) if auto_normalize else (lambda t: t)
 
         # sampling knobs that do not exist upstream
-        # Precision schedule of the ancestral chain: in the first half of a long chain (t >= T / 2, T >= 500) the
+        # Precision schedule of the ancestral chain: in the first half of a long chain (t >= T / 2, T >= 1000) the
         # 3x3 convolutions run on two fp16 products per multiply instead of three bf16 ones, in its first quarter on one -- the chain damps what that costs
         # (tests/studies/error_budget_study.py; tests/test_gpu_timed_path.py::test_full_length_chain_drift_vs_oracle holds the bound).
         # False: split-bf16 x3 at every step.  HICDIFF_EARLY_F16=0 turns it off for a process.
@@ -248,8 +248,9 @@ class DiffusionCore(nn.Module):
         return c
 
     def _early_band(self, t_idx: int) -> bool:
-        """Does step t take the two-product arithmetic?  Long chains only (the 50-step chains amplify a per-step error 4-7 x more: each of
-        their steps is twenty steps' worth of posterior_mean_coef1), their first half only, networks that declare EARLY_BAND_OK (what the CPU
+        """Does step t take the two-product arithmetic?  Chains of at least 1000 steps only -- the lengths measured (1000; SR3's 2000); a 50-step
+        chain amplifies a per-step error 4-7 x more (each of its steps is twenty steps' worth of posterior_mean_coef1) and a 500-step one would
+        sit in between with no measurement behind it --, their first half only, networks that declare EARLY_BAND_OK (what the CPU
         study and the GPU drift runs covered) -- and the LINEAR beta schedule only (EARLY_BAND_SCHEDULES): what a chain forgives depends on how
         long it stays at low noise.  The same bands on the reference's default sigmoid schedule (alphas_cumprod 0.50 at T/2 against the linear
         schedule's 0.078) and on the cosine one ended 1.0-2.4e-3 from the x3 chain, and bands moved to where those chains are as noisy as
@@ -259,7 +260,7 @@ class DiffusionCore(nn.Module):
         reference's, and the one measured: with pred_x0 / pred_v the network's error reaches x0 with gain 1 instead of
         sqrt_recipm1_alphas_cumprod[t], which is 0.01 at the end of a chain, exactly where the late tier would put it."""
         T = self.num_timesteps
-        return (bool(self.early_band_f16) and T >= 500 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
+        return (bool(self.early_band_f16) and T >= 1000 and t_idx >= int(self._band_from() * T) and bool(getattr(self.model, "EARLY_BAND_OK", False))
                 and self.__dict__.get("_beta_schedule_name") in self.EARLY_BAND_SCHEDULES and self.objective == "pred_noise")
 
     EARLY_BAND_SCHEDULES = ("linear",)     # beta schedules the precision schedule has been measured on (train.py's; BASELINE's bench configuration)
