@@ -107,7 +107,7 @@ def host_threads():
     return max(1, min(cores, int(os.environ.get("HICDIFF_CPU_THREADS", "16"))))
 
 
-def build_model(w, device):
+def build_model(w, device, beta_schedule="linear"):
     torch.manual_seed(1234)
     if w["arch"] == "unet":
         if w["cond"]:
@@ -124,7 +124,7 @@ def build_model(w, device):
             from hicdiff_amd.hicdiff import GaussianDiffusion
         net = hicedrn_Diff(self_condition=w["cond"])
     net = net.to(device)
-    diff = GaussianDiffusion(net, image_size=w["S"], timesteps=T_CHAIN, loss_type="l2", beta_schedule="linear").to(device)
+    diff = GaussianDiffusion(net, image_size=w["S"], timesteps=T_CHAIN, loss_type="l2", beta_schedule=beta_schedule).to(device)
     return net, diff
 
 
@@ -347,6 +347,9 @@ def main():
                          "total/N per GPU; reported with \"scaling\": \"strong\"")
     ap.add_argument("--chains", type=int, default=None, choices=[1, 2, 3, 4],
                     help="force one whole-batch chain or two half-batch chains per GPU (default: the library's rule, two for every replayed step: from 150 k pixels per step on)")
+    ap.add_argument("--beta-schedule", default="linear", choices=["linear", "cosine", "sigmoid"],
+                    help="beta schedule of the chain (default: train.py's linear, the headline configuration since round 1; the precision schedule "
+                         "applies to it alone -- sigmoid / cosine chains run split-bf16 x3 at every step, DESIGN.md section 4e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-table", action="store_true", help="also print one line per convolution kernel (stderr): launches, ms per step, TFLOP/s-eq, GB/s")
     ap.add_argument("--full-chain", action="store_true", help="time a whole chain: --steps becomes 1000 (t = 999 .. 0)")
@@ -376,7 +379,7 @@ def main():
     from hicdiff_amd import _lib as L
     from hicdiff_amd.sharding import all_gather_tiles
     lib = L.load()
-    net, diff = build_model(w, device)
+    net, diff = build_model(w, device, args.beta_schedule)
     B, S = w["B"], w["S"]
     diff.tile_offset = rank * B                       # noise keyed by the GLOBAL tile index
     img = diff._initial_noise((B, 1, S, S), device)
@@ -529,8 +532,8 @@ def main():
             "dtype": ("f32 (wide convs: split-bf16 x3 MFMA, fp32 accumulate" + ("; 3x3 convs of the steps t >= T/2: two fp16 MFMAs per product, t >= 3T/4: one" if early else "") + ")")
                      if split else "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['arch']} eps-net, {'conditional' if w['cond'] else 'unconditional'}, "
-                                   f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, device Philox noise",
-                       "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "parallelism": f"tile-shard x{world}",
+                                   f"1x{S}x{S} tiles, {B} tiles/GPU, ancestral DDPM T={T_CHAIN}, {args.beta_schedule} beta schedule, device Philox noise",
+                       "tiles_per_gpu": B, "tile": S, "chain_steps": T_CHAIN, "beta_schedule": args.beta_schedule, "parallelism": f"tile-shard x{world}",
                        "chains": chains,
                        **({"total_tiles": args.total_tiles} if args.total_tiles else {}),
                        "precision_schedule": (f"3x3 convs: one fp16 product per multiply for t >= {int(diff.early_band_x1_from * T_CHAIN)}, two for t >= "
