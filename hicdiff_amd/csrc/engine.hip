@@ -598,9 +598,11 @@ static int unet_attention(Run& r, const AttnW& w, const Act& x, Act* out, float*
         HD_TRY(r.alloc(std::max(slots * (32 + 32 + 32 * 32), linattn_scratch_floats(r.B, HW, heads)), &scr));
         if (qfuse || qchain) { float* wf; HD_TRY(r.alloc((size_t)r.B * wfold_bytes / sizeof(float), &wf)); wfold = (unsigned short*)wf; }
         if (!r.dry) {
-            float* pmax = scr; float* psum = pmax + slots * 32; float* pctx = psum + slots * 32;
+            const int nparts = linattn_kv_nparts(HW, C);                  // the workspace keeps its per-chunk size; the merging kernel fills a prefix
+            const size_t pslots = (size_t)r.B * heads * nparts;
+            float* pmax = scr; float* psum = pmax + pslots * 32; float* pctx = psum + pslots * 32;
             HD_TRY(launch_linattn_kv_fused(x.p, w.wkv, r.B, HW, C, pmax, psum, pctx, r.st));
-            HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nsplit, HW, ctx, r.st));
+            HD_TRY(launch_linattn_combine(pmax, psum, pctx, r.B, heads, nparts, HW, ctx, r.st));
             if (r.c->capture) { Act ca{}; ca.B = r.B; ca.H = heads; ca.W = 32; ca.C = 32; ca.p = ctx; HD_TRY(probe(r, w.name + ".ctx", ca)); }
             if (qfuse || qchain) HD_TRY(launch_linattn_fold_out(w.out.w, ctx, r.B, w.out.CoutPad, wfold, r.st, qchain ? 1 : 0));
             else { HD_TRY(launch_linattn_apply(qkv.p, 128, ctx, r.B, HW, heads, att.p, r.st)); HD_TRY(probe(r, w.name + ".att", att)); }

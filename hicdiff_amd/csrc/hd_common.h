@@ -170,6 +170,7 @@ int launch_linattn_combine(const float* pmax, const float* psum, const float* pc
                            hipStream_t st);
 int launch_pack_kv(const float* wqkv, const float* g, int C, unsigned short* dst, hipStream_t st);
 int linattn_kv_nsplit(int HW);
+int linattn_kv_nparts(int HW, int C);   // partials per (sample, head) written by launch_linattn_kv_fused (<= linattn_kv_nsplit: the 64-channel kernel merges its chunks)
 int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
                             hipStream_t st);
 int launch_pack_q(const float* wqkv, const float* g, int C, unsigned short* dst, hipStream_t st);

@@ -143,25 +143,30 @@ __global__ __launch_bounds__(256) void linattn_kv_fused_kernel(const float* __re
     }
 
     // ---- column softmax statistics of k over the chunk's tokens (rows = registers), p = exp(k - max)
+    // Tokens past the end of the map (the last chunk of a map whose size is no multiple of 64): their operand rows were staged as zeros, so
+    // their v is exactly 0 already; their k is sent to -3e38 here -- out of the maximum, exp() = 0 -- in a block the full chunks jump over
+    // (a per-element select in the loops below cost ~160 of the ~1400 instructions a chunk issues).
+    if (ntok < KV_TOK) {
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= ntok) acc[tm][0][r] = -3.0e38f;
+    }
     float mx = -3.0e38f;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (t < ntok) mx = fmaxf(mx, acc[tm][0][r]);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[tm][0][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float ps = 0.f;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float pe = t < ntok ? __expf(acc[tm][0][r] - mx) : 0.f;
+            const float pe = __expf(acc[tm][0][r] - mx);
             acc[tm][0][r] = pe;
             ps += pe;
-            if (t >= ntok) acc[tm][1][r] = 0.f;                // v of tokens past the end
         }
     ps += __shfl_xor(ps, 32);
 
@@ -198,6 +203,12 @@ __global__ __launch_bounds__(256) void linattn_kv_fused_kernel(const float* __re
 // is multiplied, a chunk's two slices are staged together (two barriers per chunk), and each chunk emits the same flash-style partials
 // as before (no state is carried from chunk to chunk, so the combine kernel and every result bit stay as they were).
 // LDS: 64 KB weights + 16 KB token tiles = half a CU: two workgroups per CU.
+// MERGE (round 4, default): the workgroup carries running column maxima, exp-sums and ONE context across its chunks (online softmax: the
+// exponentials of a chunk are taken against max(running, chunk) and only the running context is rescaled -- its rows sit on the register
+// index, so the row factors come from their lanes by ds_bpermute) and writes one partial per GROUP of cpw chunks: at 256 x 64 x 64 the
+// per-chunk form wrote 268 MB of partials, as much as it read, and linattn_combine read them back.  cpw is a function of the map size
+// only (kv64_cpw), never of the batch, so a tile's bits do not depend on what it is batched with.
+template <bool MERGE>
 __global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wkv, int HW, int nsplit,
                                                               int cpw, float* __restrict__ pmax, float* __restrict__ psum, float* __restrict__ pctx) {
     constexpr int C = 64, CK = 32, ROWB = 4 * CK, heads = 4, D = 32;
@@ -240,6 +251,10 @@ __global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __res
     const int xdst = (part >> 1) * 64 * ROWB + tok * ROWB;           // this thread's token row in its slice's tile
     const int xsw = (tok >> 1) & 7, xp0 = (part & 1) * 2;            // its two 8-channel groups are pieces xp0, xp0 + 1 (hi) and + 4 (lo)
 
+    float m_run = -3.0e38f, s_run = 0.f;               // MERGE: column d = l31 of this head (both halves hold the same values)
+    f32x16 ctx_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ctx_run[r] = 0.f;
     for (int sp = sp0; sp < sp1; ++sp) {
         const int n0 = sp * KV_TOK, ntok = min(KV_TOK, HW - n0);
         const bool tvalid = tok < ntok;
@@ -314,30 +329,44 @@ __global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __res
             }
 
         // ---- column softmax statistics of k over the chunk's tokens (rows = registers), p = exp(k - max)
+        if (ntok < KV_TOK) {                     // tokens past the end of the map: see linattn_kv_fused_kernel
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half >= ntok) acc[tm][0][r] = -3.0e38f;
+        }
         float mx = -3.0e38f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (t < ntok) mx = fmaxf(mx, acc[tm][0][r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, acc[tm][0][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if constexpr (MERGE) {
+            // the running state moves to the new maxima: exp(m_run - m_new) is 0 on the first chunk (m_run = -3e38) and 1 where the maximum stays
+            const float m_new = fmaxf(m_run, mx);
+            const float f_old = __expf(m_run - m_new);
+            s_run *= f_old;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctx_run[r] *= __shfl(f_old, (r & 3) + 8 * (r >> 2) + 4 * half);     // row d of the context <- lane d
+            m_run = m_new; mx = m_new;
+        }
         float ps = 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int t = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                const float pe = t < ntok ? __expf(acc[tm][0][r] - mx) : 0.f;
+                const float pe = __expf(acc[tm][0][r] - mx);
                 acc[tm][0][r] = pe;
                 ps += pe;
-                if (t >= ntok) acc[tm][1][r] = 0.f;                // v of tokens past the end
             }
         ps += __shfl_xor(ps, 32);
         f32x16 ctx;
+        if constexpr (MERGE) { ctx = ctx_run; s_run += ps; }
+        else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+            for (int r = 0; r < 16; ++r) ctx[r] = 0.f;
+        }
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -349,7 +378,12 @@ __global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __res
                 ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vl, ctx, 0, 0, 0);
                 ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph, vh, ctx, 0, 0, 0);
             }
-        const size_t slot = ((size_t)b * heads + w) * nsplit + sp;
+        if constexpr (MERGE) {
+            ctx_run = ctx;
+            if (sp + 1 < sp1) continue;                              // one partial per group, after its last chunk
+            ps = s_run;
+        }
+        const size_t slot = MERGE ? ((size_t)b * heads + w) * groups + blockIdx.x % groups : ((size_t)b * heads + w) * nsplit + sp;
         if (half == 0) { pmax[slot * D + l31] = mx; psum[slot * D + l31] = ps; }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -383,21 +417,44 @@ int launch_pack_kv(const float* wqkv, const float* g, int C, unsigned short* dst
 
 int linattn_kv_nsplit(int HW) { return (HW + KV_TOK - 1) / KV_TOK; }
 
+static bool kv64_old() { static const bool v = getenv("HICDIFF_KV64_OLD") && atoi(getenv("HICDIFF_KV64_OLD")) != 0; return v; }       // A/B switch of the round-3 kernel
+static bool kv64_merge() { static const bool v = !(getenv("HICDIFF_KV64_MERGE") && atoi(getenv("HICDIFF_KV64_MERGE")) == 0); return v; }  // 0: one partial per chunk (the round-3 / early round-4 form)
+
+// chunks per workgroup of the merging 64-channel kernel: about eight groups per sample, at most 16 chunks each -- by the MAP SIZE only
+// (what a group covers decides the order of the sums, so it must not follow the batch)
+static int kv64_cpw(int HW) {
+    const int nsplit = linattn_kv_nsplit(HW);
+    return std::min(16, std::max(1, (nsplit + 7) / 8));
+}
+
+// partials per (sample, head) that launch_linattn_kv_fused writes and linattn_combine reads
+int linattn_kv_nparts(int HW, int C) {
+    const int nsplit = linattn_kv_nsplit(HW);
+    if (C == 64 && !kv64_old() && kv64_merge()) { const int cpw = kv64_cpw(HW); return (nsplit + cpw - 1) / cpw; }
+    return nsplit;
+}
+
 int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, int HW, int C, float* pmax, float* psum, float* pctx,
                             hipStream_t st) {
     const int nsplit = linattn_kv_nsplit(HW);
     const dim3 grid((unsigned)(B * nsplit));
-    static const bool old64 = getenv("HICDIFF_KV64_OLD") && atoi(getenv("HICDIFF_KV64_OLD")) != 0;      // A/B switch of the round-3 kernel
-    if (C == 64 && !old64) {
-        if (!hd_raise_dynamic_lds(reinterpret_cast<const void*>(linattn_kv64_kernel), 80 * 1024)) {
+    if (C == 64 && !kv64_old()) {
+        const bool merge = kv64_merge();
+        const void* fn = merge ? reinterpret_cast<const void*>(linattn_kv64_kernel<true>) : reinterpret_cast<const void*>(linattn_kv64_kernel<false>);
+        if (!hd_raise_dynamic_lds(fn, 80 * 1024)) {
             hd_set_error("linattn_kv64: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed"); return -3;
         }
-        // chunks per workgroup: as many as leave about two rounds of workgroups on 256 CUs x 2 slots, at most 16 (by the map size and the
-        // batch only in the grid shape -- the partials do not depend on how chunks are grouped)
-        int cpw = 16;
-        while (cpw > 1 && (long long)B * ((nsplit + cpw - 1) / cpw) < 1024) cpw >>= 1;
-        const int groups = (nsplit + cpw - 1) / cpw;
-        hipLaunchKernelGGL(linattn_kv64_kernel, dim3((unsigned)(B * groups)), dim3(256), 80 * 1024, st, x, wkv, HW, nsplit, cpw, pmax, psum, pctx);
+        if (merge) {
+            const int cpw = kv64_cpw(HW), groups = (nsplit + cpw - 1) / cpw;
+            hipLaunchKernelGGL(linattn_kv64_kernel<true>, dim3((unsigned)(B * groups)), dim3(256), 80 * 1024, st, x, wkv, HW, nsplit, cpw, pmax, psum, pctx);
+        } else {
+            // chunks per workgroup: as many as leave about two rounds of workgroups on 256 CUs x 2 slots, at most 16 (by the map size and the
+            // batch only in the grid shape -- the per-chunk partials do not depend on how chunks are grouped)
+            int cpw = 16;
+            while (cpw > 1 && (long long)B * ((nsplit + cpw - 1) / cpw) < 1024) cpw >>= 1;
+            const int groups = (nsplit + cpw - 1) / cpw;
+            hipLaunchKernelGGL(linattn_kv64_kernel<false>, dim3((unsigned)(B * groups)), dim3(256), 80 * 1024, st, x, wkv, HW, nsplit, cpw, pmax, psum, pctx);
+        }
     } else if (C == 64) hipLaunchKernelGGL(linattn_kv_fused_kernel<64>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
     else if (C == 128) hipLaunchKernelGGL(linattn_kv_fused_kernel<128>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);
     else if (C == 256) hipLaunchKernelGGL(linattn_kv_fused_kernel<256>, grid, dim3(256), 0, st, x, wkv, HW, nsplit, pmax, psum, pctx);

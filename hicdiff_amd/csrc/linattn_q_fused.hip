@@ -165,6 +165,17 @@ __global__ __launch_bounds__(512) void linattn_q_fused_kernel(const float* __res
     }
 
     // ---- epilogue through the wave's stage [32 px][68 floats]: rows become contiguous, 16 lanes per row
+    // The residual rows (x again, in the epilogue's lane layout: mostly L2 / MALL hits) are requested BEFORE the barrier, so that their
+    // round trip runs under the wait for the other waves and the staging instead of in front of the first row pass.
+    const int cq = lane & 15, rg = lane >> 4;           // 4 channels, rows rg, rg + 4, ...
+    float4 rr[8];
+#ifndef HD_QF_LATE_RESIDUAL   // A/B builds (make TAG=_qlate EXTRA=-DHD_QF_LATE_RESIDUAL): the form before, one exposed load per row pass
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int nn = n0 + pass * 4 + rg;
+        rr[pass] = *reinterpret_cast<const float4*>(x + ((size_t)b * HW + (nn < HW ? nn : 0)) * C + cq * 4);
+    }
+#endif
     __syncthreads();                      // the stage overlays the weight images: every wave has left the head loop
     float* sf = reinterpret_cast<float*>(stg);
 #pragma unroll
@@ -172,21 +183,22 @@ __global__ __launch_bounds__(512) void linattn_q_fused_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) sf[((r & 3) + 8 * (r >> 2) + 4 * half) * 68 + tn * 32 + l31] = y[tn][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int cq = lane & 15, rg = lane >> 4;           // 4 channels, rows rg, rg + 4, ...
     const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 g4 = *reinterpret_cast<const float4*>(gout + cq * 4);
 #pragma unroll
     for (int pass = 0; pass < 8; ++pass) {
         const int row = pass * 4 + rg, nn = n0 + row;
         const size_t o = ((size_t)b * HW + (nn < HW ? nn : 0)) * C + cq * 4;
-        const float4 rr = *reinterpret_cast<const float4*>(x + o);
+#ifdef HD_QF_LATE_RESIDUAL
+        rr[pass] = *reinterpret_cast<const float4*>(x + o);
+#endif
         const float4 a4 = *reinterpret_cast<const float4*>(sf + row * 68 + cq * 4);
         float v0 = a4.x + b4.x, v1 = a4.y + b4.y, v2 = a4.z + b4.z, v3 = a4.w + b4.w;
         const float mean = allsum16((v0 + v1) + (v2 + v3)) * (1.f / C);
         v0 -= mean; v1 -= mean; v2 -= mean; v3 -= mean;
         const float var = allsum16(v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3) * (1.f / C);
         const float r2 = rsqrtf(var + 1e-5f);
-        const f32x4 o4 = {v0 * r2 * g4.x + rr.x, v1 * r2 * g4.y + rr.y, v2 * r2 * g4.z + rr.z, v3 * r2 * g4.w + rr.w};
+        const f32x4 o4 = {v0 * r2 * g4.x + rr[pass].x, v1 * r2 * g4.y + rr[pass].y, v2 * r2 * g4.z + rr[pass].z, v3 * r2 * g4.w + rr[pass].w};
         if (nn < HW) *reinterpret_cast<f32x4*>(out + o) = o4;
     }
 }

@@ -98,6 +98,19 @@ def test_tiny_unet_eps_vs_oracle_ragged_batches(B, S):
     assert rel_err(ref(x, t), m(x.cuda(), t.cuda())) < EPS_TOL
 
 
+@pytest.mark.parametrize("S", [20, 36])
+def test_unet64_eps_vs_oracle_partial_attention_chunk(S):
+    """64-channel LinearAttention on maps of 400 / 1296 tokens: the last 64-token chunk of the fused K/V kernel is partial (16 tokens) and
+    -- with the chunks of a workgroup merged online -- closes a group of its own or shares one.  (With four levels the full-resolution map
+    is always a multiple of 64 tokens, so the product shapes never take that path.)"""
+    m, ref = product_unet("uncond", 64, (1, 2)), oracle_unet("uncond", 64, (1, 2))
+    x = tiles(300 + S, 3, S)
+    t = torch.tensor([3, 480, 999])
+    out = m(x.cuda(), t.cuda())
+    assert rel_err(ref(x, t), out) < EPS_TOL
+    assert torch.equal(out[1:2], m(x[1:2].cuda(), t[1:2].cuda()))
+
+
 def test_hicedrn_eps_vs_oracle_batch_of_tiles():
     m, ref = product_hicedrn("uncond", 2), oracle_hicedrn("uncond", 2)
     x = tiles(7, 6, 40)
