@@ -51,7 +51,7 @@ PEAK_HBM_GBS = 8000.0
 T_CHAIN = 1000
 # HBM bytes per launch of each kernel from the FETCH_SIZE / WRITE_SIZE passes of this round (separate rocprofv3
 # --pmc runs of this script; profiles/README.md): a recorded measurement, reported as roofline.traffic with its source.
-TRAFFIC_FILE = {"unet64": os.path.join(ROOT, "profiles", "r04_z_unet64_b256_hbm_traffic.json")}
+TRAFFIC_FILE = {"unet64": os.path.join(ROOT, "profiles", "r04_s3_unet64_b256_hbm_traffic.json")}
 
 
 def recorded_traffic(workload, kernel, batch, default_batch):

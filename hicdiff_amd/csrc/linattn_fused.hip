@@ -477,11 +477,11 @@ int launch_linattn_kv_fused(const float* x, const unsigned short* wkv, int B, in
 __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __restrict__ wout, const float* __restrict__ ctx, int CoutPad,
                                                                unsigned short* __restrict__ dst, int permute) {
     constexpr int D = 32;
-    __shared__ float cs[D][D + 1];
+    __shared__ __attribute__((aligned(16))) float cst[D][D];                 // the context TRANSPOSED, [e][d]: a thread's eight d are two 16-byte broadcast reads
     __shared__ float ws[D][64];
     __shared__ __attribute__((aligned(16))) unsigned short img[64 * 64];     // 8 KB: permute ? [64 o][32 hi | 32 lo] : [2 k-steps][64 o][16 hi | 16 lo]
     const int bh = blockIdx.x, h = bh & 3, o0 = blockIdx.y * 64, tid = threadIdx.x;       // heads = 4
-    for (int i = tid; i < D * D; i += 256) cs[i / D][i % D] = ctx[(size_t)bh * D * D + i];
+    for (int i = tid; i < D * D; i += 256) cst[i / D][i % D] = ctx[(size_t)bh * D * D + (i % D) * D + i / D];   // lanes along d: conflict-free LDS writes, 4 KB of strided reads from L2
     for (int i = tid; i < D * 64; i += 256) ws[i >> 6][i & 63] = wout[(size_t)(h * D + (i >> 6)) * CoutPad + o0 + (i & 63)];   // packed fp32 [Cin = 128][CoutPad]
     __syncthreads();
     const int o = tid & 63, dq = tid >> 6;
@@ -491,8 +491,9 @@ __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __re
 #pragma unroll 8
     for (int e = 0; e < D; ++e) {
         const float wv = ws[e][o];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += wv * cs[dq * 8 + j][e];
+        const float4 c0 = *reinterpret_cast<const float4*>(&cst[e][dq * 8]), c1 = *reinterpret_cast<const float4*>(&cst[e][dq * 8 + 4]);
+        acc[0] += wv * c0.x; acc[1] += wv * c0.y; acc[2] += wv * c0.z; acc[3] += wv * c0.w;
+        acc[4] += wv * c1.x; acc[5] += wv * c1.y; acc[6] += wv * c1.z; acc[7] += wv * c1.w;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
