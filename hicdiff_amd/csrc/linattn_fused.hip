@@ -212,6 +212,8 @@ template <bool MERGE>
 __global__ __launch_bounds__(256, 2) void linattn_kv64_kernel(const float* __restrict__ x, const unsigned short* __restrict__ wkv, int HW, int nsplit,
                                                               int cpw, float* __restrict__ pmax, float* __restrict__ psum, float* __restrict__ pctx) {
     constexpr int C = 64, CK = 32, ROWB = 4 * CK, heads = 4, D = 32;
+    // (Tried: starting the workgroups 256 .. 511, 768 .. of the grid -- the second one of each CU -- 1 to 5 x 1024 cycles late, so that their VALU
+    // phases meet the first one's MFMA phases: 118.8 us without, 120.2 - 124.9 with; profiles/r04_s4_linattn_kv64_stagger_negative.txt.)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ws = smem;                                   // [2 slices][256 rows][128 B]
     char* Xs = smem + 2 * 256 * ROWB;                  // [2 slices][64 tokens][128 B]
@@ -481,8 +483,19 @@ __global__ __launch_bounds__(256) void linattn_fold_out_kernel(const float* __re
     __shared__ float ws[D][64];
     __shared__ __attribute__((aligned(16))) unsigned short img[64 * 64];     // 8 KB: permute ? [64 o][32 hi | 32 lo] : [2 k-steps][64 o][16 hi | 16 lo]
     const int bh = blockIdx.x, h = bh & 3, o0 = blockIdx.y * 64, tid = threadIdx.x;       // heads = 4
-    for (int i = tid; i < D * D; i += 256) cst[i / D][i % D] = ctx[(size_t)bh * D * D + (i % D) * D + i / D];   // lanes along d: conflict-free LDS writes, 4 KB of strided reads from L2
-    for (int i = tid; i < D * 64; i += 256) ws[i >> 6][i & 63] = wout[(size_t)(h * D + (i >> 6)) * CoutPad + o0 + (i & 63)];   // packed fp32 [Cin = 128][CoutPad]
+    // twelve loads per thread, all issued before the first LDS write (constant trip counts: as `for (i = tid; i < N; i += 256)` loops hipcc kept
+    // them rolled, one L2 round trip per iteration)
+    {
+        float cr[4], wr[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = tid + k * 256; cr[k] = ctx[(size_t)bh * D * D + (i % D) * D + i / D]; }   // lanes along d: conflict-free LDS writes, 4 KB of strided reads from L2
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = tid + k * 256; wr[k] = wout[(size_t)(h * D + (i >> 6)) * CoutPad + o0 + (i & 63)]; }   // packed fp32 [Cin = 128][CoutPad]
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = tid + k * 256; cst[i / D][i % D] = cr[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int i = tid + k * 256; ws[i >> 6][i & 63] = wr[k]; }
+    }
     __syncthreads();
     const int o = tid & 63, dq = tid >> 6;
     float acc[8];

@@ -81,15 +81,23 @@ __global__ __launch_bounds__(512) void linattn_q_fused_kernel(const float* __res
     asm volatile("v_mov_b32 %0, %1" : "=v"(rs) : "v"(st.y));
 
     // ---- the two weight images -> LDS (16 bytes per lane; rows are 128 B of data + pad)
-    for (int i = tid; i < 2 * 128 * 8; i += 512) {
-        const int row = i >> 3, piece = i & 7;
-        *reinterpret_cast<uint4*>(WQs + row * QF_PITCH + piece * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wq) + (size_t)row * 128 + piece * 16);
-    }
+    // Both images are 2048 pieces of 16 bytes = four per thread each: all eight loads are issued before the first LDS write.  (As two
+    // `for (i = tid; i < 2048; i += 512)` loops hipcc kept them rolled -- load, wait, write, four times each: eight L2 round trips in a row
+    // in front of the first barrier of every workgroup.)
     {
         const char* wf = reinterpret_cast<const char*>(wfold) + (size_t)b * (4 * 64 * 128);
-        for (int i = tid; i < 4 * 64 * 8; i += 512) {
-            const int row = i >> 3, piece = i & 7;
-            *reinterpret_cast<uint4*>(WFs + row * QF_PITCH + piece * 16) = *reinterpret_cast<const uint4*>(wf + (size_t)row * 128 + piece * 16);
+        uint4 wreg[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * 512, row = i >> 3, piece = i & 7;
+            wreg[k] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wq) + (size_t)row * 128 + piece * 16);
+            wreg[4 + k] = *reinterpret_cast<const uint4*>(wf + (size_t)row * 128 + piece * 16);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = tid + k * 512, row = i >> 3, piece = i & 7;
+            *reinterpret_cast<uint4*>(WQs + row * QF_PITCH + piece * 16) = wreg[k];
+            *reinterpret_cast<uint4*>(WFs + row * QF_PITCH + piece * 16) = wreg[4 + k];
         }
     }
     bf16x8 ah[4], al[4];

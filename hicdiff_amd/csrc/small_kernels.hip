@@ -90,11 +90,24 @@ __global__ __launch_bounds__(256) void conv_first_lanes_kernel(const float* __re
     const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
     const int co = blockIdx.y * 64 + lane;
 
-    for (int i = tid; i < CIN * 2 * LH * LW; i += 256) {
-        const int c = i % LW, r = (i / LW) % LH, sh = (i / (LW * LH)) & 1, ci = i / (2 * LW * LH);
-        const int yy = y0 + r - R, xx = x0 + c + sh - R;
-        const float* src = (CIN == 2 && ci == 0) ? cond : x;
-        (&win[0][0][0][0])[i] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? src[((size_t)b * S + yy) * S + xx] : 0.f;
+    // the window: every thread's elements are requested before the first one is written to LDS (a constant trip count and clamped addresses --
+    // as a `for (i = tid; i < N; i += 256)` loop with the load under the bounds test, hipcc kept it rolled: one exposed round trip per element)
+    {
+        constexpr int NW = CIN * 2 * LH * LW, NIT = (NW + 255) / 256;
+        float wv[NIT];
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int i = min(tid + k * 256, NW - 1);
+            const int c = i % LW, r = (i / LW) % LH, sh = (i / (LW * LH)) & 1, ci = i / (2 * LW * LH);
+            const int yy = y0 + r - R, xx = x0 + c + sh - R;
+            const float* src = (CIN == 2 && ci == 0) ? cond : x;
+            const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+            const float v = src[((size_t)b * S + (in ? yy : 0)) * S + (in ? xx : 0)];
+            wv[k] = in ? v : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k)
+            if (tid + k * 256 < NW) (&win[0][0][0][0])[tid + k * 256] = wv[k];
     }
     // this lane's filter, torch layout [Cout][CIN][KS][KS]: pairs (w[dy][2k], w[dy][2k + 1]), the last pair of an odd row padded with 0
     f32x2 wp[CIN][KS][NP];

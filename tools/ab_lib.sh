@@ -19,4 +19,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_product -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained-budget 0 --chains 1 > $R/$O/prof_product.log 2>&1
 export HICDIFF_HIP_LIB=$PREV
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof_prev -o p -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --sustained-budget 0 --chains 1 > $R/$O/prof_prev.log 2>&1
-grep -E "linattn_fold_out" $R/$O/prof_product/*kernel_stats.csv $R/$O/prof_prev/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-200
+grep -E "linattn_fold_out|linattn_q_fused|conv_first_lanes" $R/$O/prof_product/*kernel_stats.csv $R/$O/prof_prev/*kernel_stats.csv | cut -d, -f1-4 | cut -c1-200
