@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void linattn_kv_fused_kernel(const float* __re
 // memory traffic are weights from L2 and every workgroup is a chain of exposed latencies (x, LayerNorm, weights, MFMA) -- 173 us per launch
 // at 256 x 64 x 64, 1.5 TB/s.  Here a workgroup loads the image once (LDS-DMA, both 32-channel slices, unpadded rows with XOR-swizzled
 // 16-byte pieces: 64 KB), then walks up to CPW chunks of its sample: the next chunk's token rows are requested while the current chunk
-// is multiplied, a chunk's two slices are staged together (two barriers per chunk), and each chunk emits the same flash-style partials
-// as before (no state is carried from chunk to chunk, so the combine kernel and every result bit stay as they were).
+// is multiplied, a chunk's two slices are staged together (two barriers per chunk).  MERGE = false (round 3): each chunk emits the same
+// flash-style partials as the kernel above (no state is carried from chunk to chunk; the combine kernel and every result bit as they were).
 // LDS: 64 KB weights + 16 KB token tiles = half a CU: two workgroups per CU.
 // MERGE (round 4, default): the workgroup carries running column maxima, exp-sums and ONE context across its chunks (online softmax: the
 // exponentials of a chunk are taken against max(running, chunk) and only the running context is rescaled -- its rows sit on the register
