@@ -31,6 +31,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GOMP_SPINCOUNT", "20000")   # the cpu_baseline leg runs one OpenMP worker per granted core: bounded barrier spins (tests/conftest.py), set before torch loads libgomp
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

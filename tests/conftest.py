@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The CPU oracle runs on torch's OpenMP pool (libgomp) with one thread per granted core.  With exactly as many workers as cores, ONE more runnable
+# thread in the process parks a worker behind seven others that spin at the region's barrier for libgomp's default 300 000 iterations: every
+# parallel region then costs a scheduler tick instead of microseconds -- seen here as the oracle chain tests taking 15 minutes instead of 13 s in
+# two of five runs of this suite (700 % CPU, no progress).  A bounded spin keeps the fast path (31 s vs 28 s for the chain tests; 1000: 59 s) and
+# lets a parked worker run.  Must be set before torch loads libgomp; the thread count itself stays (test_ddim's margin is thread-count sensitive).
+os.environ.setdefault("GOMP_SPINCOUNT", "20000")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
